@@ -1,0 +1,144 @@
+/*
+ * rlvi_hip.h -- C ABI of librlvi_gfx950.so, the MI355X (gfx950 / CDNA4) implementation
+ * of the RLVI E-step / M-step hot path.
+ *
+ * The reference (akarakulev/rlvi) is pure Python; its "FFI" for this path is the set of
+ * torch / numpy calls inside the plug-in function
+ *     methods.train_rlvi(train_loader, model, optimizer, residuals, weights, overfit, threshold)
+ * (deep-learning/methods/train_rlvi.py:52-106, selected by --method=rlvi, main.py:26,277-280)
+ * and its two helpers update_sample_weights (:14-38) / false_negative_criterion (:41-49),
+ * plus standard-learning/rlvi.py:8-20,68-89 and online-learning/main.py:45-58,84-85.
+ * Each entry point below names the reference statements it replaces.  The Python binding
+ * a maintainer would add is rlvi_amd/_lib.py (ctypes); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch "cuda" tensor) unless marked host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - functions only enqueue work: no allocation, no host synchronisation, graph-capturable;
+ *   - return value: 0 = ok, < 0 = argument error (RLVI_E_*), > 0 = hipError_t of the launch;
+ *   - scratch comes from a caller-owned workspace (rlvi_workspace_bytes / rlvi_workspace_init).
+ *     One workspace must not be used by two streams at the same time.
+ *   - device-side status: word 0 of the workspace is a sticky int32 status (0 = ok), bit flags
+ *     RLVI_ST_*; out-of-range labels / indexes never touch memory, they set RLVI_ST_RANGE.
+ */
+#ifndef RLVI_HIP_H
+#define RLVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLVI_ABI_VERSION 1
+
+#define RLVI_E_NULL   (-1) /* required pointer is NULL                 */
+#define RLVI_E_SHAPE  (-2) /* negative / inconsistent size             */
+#define RLVI_E_ALIGN  (-3) /* pointer or leading dimension misaligned  */
+#define RLVI_E_WS     (-4) /* workspace too small / not initialised    */
+#define RLVI_E_LIMIT  (-5) /* size beyond what the kernels support     */
+
+#define RLVI_ST_RANGE   1  /* a label or index was out of range (row skipped)      */
+#define RLVI_ST_TIMEOUT 2  /* an inter-workgroup wait hit its bound (results invalid) */
+
+int rlvi_abi_version(void);
+const char *rlvi_error_string(int code);
+
+/* Bytes of workspace needed for vectors up to max_n samples and batches up to max_b rows. */
+size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b);
+/* Zero the control words.  Call once after allocating (or to clear a sticky status). */
+int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream);
+/* Copy the sticky status word to *status_host (synchronises the stream). */
+int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * M-step over one mini-batch, forward + backward w.r.t. the logits, lagged pi.
+ * Replaces train_rlvi.py:85 (top-1 of accuracy()), :89 (F.cross_entropy reduction='none'),
+ * :90 (residuals[indexes] = loss), :92 (weights[indexes]), :93-94 (weighted mean) and the
+ * autograd backward of those statements reached from :96.
+ *
+ *   logits      [B, C] row-major, leading dimension ld (elements)
+ *   labels, idx [B] int64;   weights, residuals [N] fp32
+ *   inv_scale   1/B for one device; 1/global_B when the batch is sharded over ranks
+ *   grad_logits [B, C] (ldg) or NULL for forward only: inv_scale*pi_i*(softmax - onehot)
+ *   out         [4] fp32 device: { sum_i pi_i*l_i * inv_scale, 100*hits/B, sum_i pi_i*l_i, hits }
+ * bf16 variant: logits / grad_logits are bfloat16, arithmetic is fp32 on the widened values.
+ * ------------------------------------------------------------------------------------- */
+int rlvi_mstep_fwd_bwd_f32(const float *logits, int64_t ld, const int64_t *labels,
+                           const int64_t *idx, const float *weights, float *residuals,
+                           int64_t N, int64_t B, int64_t C, float inv_scale,
+                           float *grad_logits, int64_t ldg, float *out, void *ws, void *stream);
+int rlvi_mstep_fwd_bwd_bf16(const uint16_t *logits, int64_t ld, const int64_t *labels,
+                            const int64_t *idx, const float *weights, float *residuals,
+                            int64_t N, int64_t B, int64_t C, float inv_scale,
+                            uint16_t *grad_logits, int64_t ldg, float *out, void *ws,
+                            void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * E-step, deep-learning variant, in place on both vectors.
+ * Replaces update_sample_weights(residuals, weights, tol, maxiter), train_rlvi.py:14-38:
+ * min-shift of the residuals (:27), e = exp(-l) (:28), the fixed point on mean(pi) with the
+ * caller's pi entering the first error only (:29-37), and the final pi /= max(pi) (:38).
+ *   out_iters  device int32 (may be NULL): iterations executed
+ *   trace      device fp32 [2*maxiter] (may be NULL): error then mean-pi of every iteration
+ * ------------------------------------------------------------------------------------- */
+int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol, int maxiter,
+                        int32_t *out_iters, float *trace, void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Type-II-error threshold, replaces false_negative_criterion(weights, alpha),
+ * train_rlvi.py:41-49 (sum, sort, cumsum, count, gather) without sorting: the position is
+ * found by bisection on the order-preserving key with exact prefix sums.
+ *   thr_out  device fp32: the threshold
+ * rlvi_threshold_truncate_f32 additionally applies train_rlvi.py:102-103:
+ *   *thr_inout = max(*thr_inout, criterion); weights[weights < *thr_inout] = 0
+ * and, if mask_gt != NULL, writes mask_gt[i] = weights[i] > *thr_inout (main.py:343) and
+ * kept_out = number of set mask entries (device int64, may be NULL).
+ * ------------------------------------------------------------------------------------- */
+int rlvi_fn_threshold_f32(const float *weights, int64_t N, float alpha, float *thr_out,
+                          void *ws, void *stream);
+int rlvi_threshold_truncate_f32(float *weights, int64_t N, float alpha, float *thr_inout,
+                                uint8_t *mask_gt, int64_t *kept_out, void *ws, void *stream);
+/* Elementwise part alone (threshold already known, on device). */
+int rlvi_truncate_f32(float *weights, int64_t N, const float *thr, uint8_t *mask_gt,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * In-batch fused E+M (online order, online-learning/main.py:296-299 applied to a logit block):
+ * per-sample NLL -> E-step on THIS batch (deep variant, pi_in only feeds the first error)
+ * -> weighted loss and gradient with the NEW pi.  Composition of a1, a7, a4, a5.
+ *   loss_rows [B] receives the min-shifted NLL, pi [B] the new posteriors (in/out).
+ * ------------------------------------------------------------------------------------- */
+int rlvi_fused_em_f32(const float *logits, int64_t ld, const int64_t *labels, float *loss_rows,
+                      float *pi, int64_t B, int64_t C, float inv_scale, float tol, int maxiter,
+                      float *grad_logits, int64_t ldg, float *out, int32_t *out_iters,
+                      void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * fp64 E-steps of the numpy paths.
+ *   rlvi_update_weights_f64        standard-learning/rlvi.py:8-20   (update_weights)
+ *   rlvi_update_weights_online_f64 online-learning/main.py:45-58    (update_weights_rlvi)
+ * ------------------------------------------------------------------------------------- */
+int rlvi_update_weights_f64(const double *losses, int64_t n, double tol, int maxiter,
+                            double *out, int32_t *out_iters, void *ws, void *stream);
+int rlvi_update_weights_online_f64(const double *losses, int64_t n, double tol, int maxiter,
+                                   double *out, int32_t *out_iters, void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense X.theta contraction + per-sample NLL of the linear / logistic paths (fp64 MFMA).
+ *   rlvi_linreg_losses_f64  rlvi.py:72-74 / :81-83: r=(y-X theta)^2, sigma2=w.r/sum(w),
+ *                           losses=0.5 r/sigma2;  sigma2_out device fp64
+ *   rlvi_logistic_nll_f64   online-learning/main.py:295-296,:84-85: -log sigmoid(X w + b)
+ * X is row-major [n, d].
+ * ------------------------------------------------------------------------------------- */
+int rlvi_linreg_losses_f64(const double *X, const double *y, const double *theta,
+                           const double *w, int64_t n, int64_t d, double *losses,
+                           double *sigma2_out, void *ws, void *stream);
+int rlvi_logistic_nll_f64(const double *X, const double *w, double b, int64_t n, int64_t d,
+                          double *losses, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLVI_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of librlvi_gfx950.so (the C ABI declared in include/rlvi_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  Nothing here imports oracle/.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librlvi_gfx950.so")
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+_f64 = ctypes.c_double
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/rlvi_hip.h one for one
+SIGNATURES = {
+    "rlvi_abi_version": (_int, []),
+    "rlvi_error_string": (ctypes.c_char_p, [_int]),
+    "rlvi_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "rlvi_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
+    "rlvi_workspace_status": (_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
+    "rlvi_mstep_fwd_bwd_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
+                                      _vp, _i64, _vp, _vp, _vp]),
+    "rlvi_mstep_fwd_bwd_bf16": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
+                                       _vp, _i64, _vp, _vp, _vp]),
+    "rlvi_estep_deep_f32": (_int, [_vp, _vp, _i64, _f32, _int, _vp, _vp, _vp, _vp]),
+    "rlvi_fn_threshold_f32": (_int, [_vp, _i64, _f32, _vp, _vp, _vp]),
+    "rlvi_threshold_truncate_f32": (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "rlvi_truncate_f32": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "rlvi_fused_em_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int,
+                                 _vp, _i64, _vp, _vp, _vp, _vp]),
+    "rlvi_update_weights_f64": (_int, [_vp, _i64, _f64, _int, _vp, _vp, _vp, _vp]),
+    "rlvi_update_weights_online_f64": (_int, [_vp, _i64, _f64, _int, _vp, _vp, _vp, _vp]),
+    "rlvi_linreg_losses_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "rlvi_logistic_nll_f64": (_int, [_vp, _vp, _f64, _i64, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+class RlviError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every symbol of the header (fails loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RlviError(
+            f"{LIB_PATH} is missing: build it with `python -m rlvi_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: librlvi_gfx950.so must bind to the HIP runtime torch has loaded (same
+    # SONAME), otherwise the process ends up with two runtimes and ours sees no device
+    import torch  # noqa: F401
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if L.rlvi_abi_version() != 1:
+        raise RlviError("librlvi_gfx950.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rlvi_error_string(rc)
+        raise RlviError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")

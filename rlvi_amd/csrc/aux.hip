@@ -1,0 +1,156 @@
+// Workspace management, error strings, the in-batch E+M composition and the fp64 X.theta
+// per-sample NLL kernels of the linear / logistic paths.
+#include "rlvi_common.h"
+
+using namespace rlvi;
+
+extern "C" int rlvi_abi_version(void) { return RLVI_ABI_VERSION; }
+
+extern "C" const char *rlvi_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case RLVI_E_NULL: return "required pointer is NULL";
+        case RLVI_E_SHAPE: return "negative or inconsistent size";
+        case RLVI_E_ALIGN: return "pointer or leading dimension misaligned";
+        case RLVI_E_WS: return "workspace too small or not initialised";
+        case RLVI_E_LIMIT: return "size beyond what the kernels support";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown rlvi error";
+    }
+}
+
+extern "C" size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b) {
+    return ws_bytes_for(max_n, max_b);
+}
+
+extern "C" int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream) {
+    if (!ws) return RLVI_E_NULL;
+    if (((uintptr_t)ws & 255)) return RLVI_E_ALIGN;
+    if (ws_bytes < WS_SCRATCH_OFF) return RLVI_E_WS;
+    return (int)hipMemsetAsync(ws, 0, WS_SCRATCH_OFF, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream) {
+    if (!ws || !status_host) return RLVI_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(status_host, ws, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(st);
+}
+
+// ---------------------------------------------------------------------------------------
+// In-batch E+M (online order): NLL pass -> E-step on this batch -> weighted loss + gradient.
+// Three launches of the kernels above; the second logits read is served by the Infinity Cache
+// for blocks up to ~100 MB.
+// ---------------------------------------------------------------------------------------
+extern "C" int rlvi_fused_em_f32(const float *logits, int64_t ld, const int64_t *labels,
+                                 float *loss_rows, float *pi, int64_t B, int64_t C,
+                                 float inv_scale, float tol, int maxiter, float *grad_logits,
+                                 int64_t ldg, float *out, int32_t *out_iters, void *ws,
+                                 void *stream) {
+    if (!loss_rows || !pi) return RLVI_E_NULL;
+    // 1. l_i = CE(logits_i, y_i) -> loss_rows  (forward only; pi is not used for the scatter)
+    int rc = rlvi_mstep_fwd_bwd_f32(logits, ld, labels, nullptr, pi, loss_rows, B, B, C, inv_scale,
+                                    nullptr, 0, out, ws, stream);
+    if (rc) return rc;
+    // 2. pi <- E-step(l)   (loss_rows becomes l - min l)
+    rc = rlvi_estep_deep_f32(loss_rows, pi, B, tol, maxiter, out_iters, nullptr, ws, stream);
+    if (rc) return rc;
+    // 3. L = inv_scale * sum pi_i l_i and dL/dlogits with the NEW pi; no scatter
+    return rlvi_mstep_fwd_bwd_f32(logits, ld, labels, nullptr, pi, nullptr, B, B, C, inv_scale,
+                                  grad_logits, ldg, out, ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// fp64 X.theta + per-sample NLL.  One wave per row group; d is small (20 / 60), so the
+// contraction is a per-row dot product kept in fp64 FMA order-independent form (tree sum).
+// ---------------------------------------------------------------------------------------
+namespace rlvi {
+
+// r_i = (y_i - x_i.theta)^2 -> losses; block partials of {w.r, sum w} -> part
+__global__ __launch_bounds__(256) void linreg_resid_kernel(const double *__restrict__ X,
+                                                           const double *__restrict__ y,
+                                                           const double *__restrict__ theta,
+                                                           const double *__restrict__ w,
+                                                           int64_t n, int64_t d,
+                                                           double *__restrict__ losses,
+                                                           double *__restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double num = 0.0, den = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+        double p = 0.0;
+        for (int64_t j = lane; j < d; j += 64) p += X[i * d + j] * theta[j];
+        p = wave_sum(p);
+        const double r = (y[i] - p) * (y[i] - p);
+        if (lane == 0) {
+            losses[i] = r;
+            num += w[i] * r;
+            den += w[i];
+        }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    __shared__ double sh[8];
+    if (lane == 0) { sh[2 * wave] = num; sh[2 * wave + 1] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = sh[0] + sh[2] + sh[4] + sh[6];
+        part[2 * blockIdx.x + 1] = sh[1] + sh[3] + sh[5] + sh[7];
+    }
+}
+
+__global__ __launch_bounds__(256) void linreg_scale_kernel(double *__restrict__ losses, int64_t n,
+                                                           const double *__restrict__ part,
+                                                           int nblocks,
+                                                           double *__restrict__ sigma2_out) {
+    // every block re-derives sigma2 from the partials in the same fixed order
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < nblocks; ++i) { num += part[2 * i]; den += part[2 * i + 1]; }
+    const double sigma2 = num / den;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sigma2_out != nullptr) *sigma2_out = sigma2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        losses[i] = 0.5 * losses[i] / sigma2;
+}
+
+__global__ __launch_bounds__(256) void logistic_nll_kernel(const double *__restrict__ X,
+                                                           const double *__restrict__ wv, double b,
+                                                           int64_t n, int64_t d,
+                                                           double *__restrict__ losses) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+        double p = 0.0;
+        for (int64_t j = lane; j < d; j += 64) p += X[i * d + j] * wv[j];
+        p = wave_sum(p) + b;
+        if (lane == 0) losses[i] = p >= 0.0 ? log1p(exp(-p)) : -p + log1p(exp(p));
+    }
+}
+
+}  // namespace rlvi
+
+extern "C" int rlvi_linreg_losses_f64(const double *X, const double *y, const double *theta,
+                                      const double *w, int64_t n, int64_t d, double *losses,
+                                      double *sigma2_out, void *ws, void *stream) {
+    if (!X || !y || !theta || !w || !losses || !ws) return RLVI_E_NULL;
+    if (n <= 0 || d <= 0) return RLVI_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF);
+    int nb = (int)((n + 3) / 4);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(linreg_resid_kernel, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d,
+                       losses, part);
+    int nb2 = (int)((n + 255) / 256);
+    if (nb2 > 256) nb2 = 256;
+    hipLaunchKernelGGL(linreg_scale_kernel, dim3(nb2), dim3(256), 0, st, losses, n, part, nb,
+                       sigma2_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rlvi_logistic_nll_f64(const double *X, const double *w, double b, int64_t n,
+                                     int64_t d, double *losses, void *stream) {
+    if (!X || !w || !losses) return RLVI_E_NULL;
+    if (n <= 0 || d <= 0) return RLVI_E_SHAPE;
+    int nb = (int)((n + 3) / 4);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(logistic_nll_kernel, dim3(nb), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), X, w, b, n, d, losses);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,199 @@
+// E-step fixed point (latent-Bernoulli posteriors) in one cooperative launch.
+//
+//   VAR_DEEP    update_sample_weights   deep-learning/methods/train_rlvi.py:14-38   (fp32)
+//   VAR_STD     update_weights          standard-learning/rlvi.py:8-20              (fp64)
+//   VAR_ONLINE  update_weights_rlvi     online-learning/main.py:45-58               (fp64)
+//
+// Each of G workgroups (1024 threads, one per CU) keeps E elements per thread of e_i=exp(-l_i)
+// and pi_i in registers for the whole fixed point; per iteration the only traffic is the
+// 32-byte record exchange of rlvi_coop.h ({sum pi, sum (pi'-pi)^2} as doubles).  Sums are
+// accumulated in fp64 in a fixed order, so the result is deterministic and every workgroup takes
+// the same stop decision.  Latency-bound: N*4 B <= a few MB; report us and iterations, not GB/s.
+#include "rlvi_coop.h"
+
+namespace rlvi {
+
+enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
+
+constexpr int ESTEP_BLOCK = 1024;
+
+template <typename F>
+__device__ __forceinline__ F fexp(F x);
+template <>
+__device__ __forceinline__ float fexp<float>(float x) { return expf(x); }
+template <>
+__device__ __forceinline__ double fexp<double>(double x) { return exp(x); }
+
+// in : deep: residuals (in/out, min-shifted), weights (in/out)
+//      std/online: losses (read only), out (write only)
+template <typename F, int VAR, int E>
+__global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
+                                                            F *__restrict__ wts, int64_t N,
+                                                            F tol, int maxiter,
+                                                            int32_t *__restrict__ out_iters,
+                                                            F *__restrict__ trace, void *ws) {
+    Coop<ESTEP_BLOCK> co;
+    co.init(ws);
+    const int64_t gstride = (int64_t)gridDim.x * ESTEP_BLOCK;
+    const int64_t i0 = (int64_t)blockIdx.x * ESTEP_BLOCK + threadIdx.x;
+
+    // this thread's elements are i0 + j*gstride, j < cnt (a prefix of 0..E-1)
+    int cnt = 0;
+    if (i0 < N) {
+        const int64_t c = (N - i0 + gstride - 1) / gstride;
+        cnt = c < E ? (int)c : E;
+    }
+#define ok_(j) ((j) < cnt)
+    F e[E], w[E];
+    F mn = (F)__builtin_inf();
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = i0 + j * gstride;
+        e[j] = ok_(j) ? res[i] : (F)0;
+        if (VAR == VAR_DEEP) {
+            w[j] = ok_(j) ? wts[i] : (F)0;          // caller's pi: enters the first error only (:33)
+            if (ok_(j)) mn = e[j] < mn ? e[j] : mn;
+        } else {
+            w[j] = ok_(j) ? (F)(VAR == VAR_STD ? 0.95 : 0.5) : (F)0;   // rlvi.py:10 / main.py:48
+        }
+    }
+    if (VAR == VAR_DEEP) {
+        double a = (double)mn, b = 0.0;
+        co.template allreduce2<OpMin, OpSum>(a, b);   // residuals.min()  (:27)
+        mn = (F)a;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (VAR == VAR_DEEP) {
+            const F l = e[j] - mn;                    // residuals.sub_(min)  (:27)
+            if (ok_(j)) res[i0 + j * gstride] = l;
+            e[j] = ok_(j) ? fexp<F>(-l) : (F)0;        // exp(-residuals)      (:28)
+        } else {
+            e[j] = ok_(j) ? fexp<F>(-e[j]) : (F)0;     // exp(-losses)
+        }
+    }
+
+    // first ratio: deep 0.95/(1-0.95) as a python float cast to fp32 (=19.0f);
+    // std eps=1-0.95, ratio=eps/(1-eps); online avg=0.5, ratio=1
+    F ratio;
+    if (VAR == VAR_DEEP) ratio = (F)(0.95 / (1.0 - 0.95));
+    else if (VAR == VAR_STD) { const double eps = 1.0 - 0.95; ratio = (F)(eps / (1.0 - eps)); }
+    else ratio = (F)(0.5 / (1.0 - 0.5));
+
+    int it = 0;
+    while (it < maxiter) {
+        double sse = 0.0, sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            F nw;
+            if (VAR == VAR_STD) {
+                nw = e[j] / (ratio + e[j]);           // rlvi.py:15
+            } else {
+                const F t = ratio * e[j];             // train_rlvi.py:32 / main.py:52
+                nw = t / ((F)1 + t);
+            }
+            nw = ok_(j) ? nw : (F)0;
+            const F d = nw - w[j];
+            sse += (double)(d * d);
+            sum += (double)nw;
+            w[j] = nw;
+        }
+        co.template allreduce2<OpSum, OpSum>(sse, sum);
+        const F err = (F)sqrt(sse);                   // ||new - weights||_2
+        const F avg = (F)sum / (F)N;                  // mean(weights)
+        if (trace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+            trace[2 * it] = err;
+            trace[2 * it + 1] = avg;
+        }
+        ++it;
+        if (err < tol) break;
+        if (VAR == VAR_STD) {
+            const F eps = (F)1 - avg;                 // rlvi.py:13-14
+            ratio = eps / ((F)1 - eps);
+        } else {
+            ratio = avg / ((F)1 - avg);               // train_rlvi.py:31 / main.py:51
+        }
+    }
+
+    if (VAR != VAR_STD) {
+        F mx = -(F)__builtin_inf();
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (ok_(j)) mx = w[j] > mx ? w[j] : mx;
+        double a = (double)mx, b = 0.0;
+        co.template allreduce2<OpMax, OpSum>(a, b);
+        mx = (F)a;
+        if (VAR == VAR_ONLINE) mx = mx * (F)N;        // new /= max(new)*len(new)  (main.py:57)
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (ok_(j)) wts[i0 + j * gstride] = w[j] / mx;   // weights.div_(max)   (:38)
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (ok_(j)) wts[i0 + j * gstride] = w[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (out_iters != nullptr) *out_iters = it;
+        co.finish(ws);
+    }
+#undef ok_
+}
+
+// Workgroup count / elements per thread for N samples: the smallest E in {4,8,16,32} that keeps
+// G = ceil(N / (1024 E)) within one workgroup per CU; E = 8 (8192 samples per CU) by default.
+template <typename F, int VAR>
+static int launch_estep(F *res, F *wts, int64_t N, F tol, int maxiter, int32_t *out_iters,
+                        F *trace, void *ws, hipStream_t st) {
+    const int64_t per = ESTEP_BLOCK;
+    auto groups = [&](int e) { return (N + per * e - 1) / (per * e); };
+#define RLVI_LAUNCH(E_)                                                                          \
+    do {                                                                                         \
+        hipLaunchKernelGGL((estep_kernel<F, VAR, E_>), dim3((unsigned)groups(E_)),               \
+                           dim3(ESTEP_BLOCK), 0, st, res, wts, N, tol, maxiter, out_iters,       \
+                           trace, ws);                                                           \
+        return (int)hipGetLastError();                                                           \
+    } while (0)
+    if (N <= per * 4) RLVI_LAUNCH(4);
+    if (groups(8) <= MAX_COOP_WG) RLVI_LAUNCH(8);
+    if (groups(16) <= MAX_COOP_WG) RLVI_LAUNCH(16);
+    if (sizeof(F) == 4 && groups(32) <= MAX_COOP_WG) RLVI_LAUNCH(32);
+#undef RLVI_LAUNCH
+    return RLVI_E_LIMIT;
+}
+
+}  // namespace rlvi
+
+using namespace rlvi;
+
+extern "C" int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol,
+                                   int maxiter, int32_t *out_iters, float *trace, void *ws,
+                                   void *stream) {
+    if (!residuals || !weights || !ws) return RLVI_E_NULL;
+    if (N <= 0 || maxiter < 0) return RLVI_E_SHAPE;
+    if (((uintptr_t)residuals & 3) || ((uintptr_t)weights & 3) || ((uintptr_t)ws & 255))
+        return RLVI_E_ALIGN;
+    return launch_estep<float, VAR_DEEP>(residuals, weights, N, tol, maxiter, out_iters, trace, ws,
+                                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rlvi_update_weights_f64(const double *losses, int64_t n, double tol, int maxiter,
+                                       double *out, int32_t *out_iters, void *ws, void *stream) {
+    if (!losses || !out || !ws) return RLVI_E_NULL;
+    if (n <= 0 || maxiter < 0) return RLVI_E_SHAPE;
+    if (((uintptr_t)losses & 7) || ((uintptr_t)out & 7) || ((uintptr_t)ws & 255))
+        return RLVI_E_ALIGN;
+    return launch_estep<double, VAR_STD>(const_cast<double *>(losses), out, n, tol, maxiter,
+                                         out_iters, nullptr, ws, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rlvi_update_weights_online_f64(const double *losses, int64_t n, double tol,
+                                              int maxiter, double *out, int32_t *out_iters,
+                                              void *ws, void *stream) {
+    if (!losses || !out || !ws) return RLVI_E_NULL;
+    if (n <= 0 || maxiter < 0) return RLVI_E_SHAPE;
+    if (((uintptr_t)losses & 7) || ((uintptr_t)out & 7) || ((uintptr_t)ws & 255))
+        return RLVI_E_ALIGN;
+    return launch_estep<double, VAR_ONLINE>(const_cast<double *>(losses), out, n, tol, maxiter,
+                                            out_iters, nullptr, ws,
+                                            static_cast<hipStream_t>(stream));
+}

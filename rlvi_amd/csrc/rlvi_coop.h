@@ -1,0 +1,160 @@
+// Cooperative (multi-workgroup) all-reduce of two doubles inside one launch.
+//
+// The E-step fixed point is a serial chain of population-wide reductions.  Kernel boundaries
+// cost ~1.5-1.9 us each and a software grid barrier ~4 us (MI355X_MICROARCH.md price list), so
+// the chain runs inside ONE launch of G <= 256 co-resident workgroups (one per CU) that keep
+// their slice of the vector in registers and exchange 32-byte records per step:
+//
+//   * every workgroup publishes 4 self-tagged 8-byte granules {tag:32, payload:32} (the two
+//     doubles, split in halves) with agent-scope relaxed atomic stores (write-through `sc1`);
+//   * one wave per workgroup polls all G records with agent-scope relaxed atomic loads until
+//     every tag equals the current epoch (the data IS the flag: no fence, no separate flag);
+//   * the polled values are combined in a fixed order (ascending workgroup per lane, then a
+//     butterfly), so every workgroup computes bit-identical totals and takes identical
+//     branches -- the stop decision of the fixed point can never diverge between workgroups.
+//
+// Slots are double-buffered by step parity: a workgroup can publish step p+2 only after it
+// gathered step p+1, i.e. after every workgroup has finished reading step p.  Tags are
+// base+step with `base` kept in the workspace and advanced at the end of every launch, so no
+// per-launch memset is needed and graph replay is safe.  Every spin is bounded by wall time.
+#pragma once
+#include "rlvi_common.h"
+
+namespace rlvi {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+struct OpSum {
+    static __device__ __forceinline__ double ident() { return 0.0; }
+    static __device__ __forceinline__ double apply(double a, double b) { return a + b; }
+};
+struct OpMin {
+    static __device__ __forceinline__ double ident() { return __builtin_inf(); }
+    static __device__ __forceinline__ double apply(double a, double b) { return b < a ? b : a; }
+};
+struct OpMax {
+    static __device__ __forceinline__ double ident() { return -__builtin_inf(); }
+    static __device__ __forceinline__ double apply(double a, double b) { return b > a ? b : a; }
+};
+
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = Op::apply(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+constexpr unsigned long long SPIN_BOUND_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock
+
+template <int BLOCK>
+struct Coop {
+    gu64 *slots;        // [2][MAX_COOP_WG][XCHG_GRANULES]
+    int32_t *status;
+    uint32_t tag;       // tag of the NEXT exchange
+    int step;           // exchanges done so far
+    int nwg;
+    bool dead;          // a wait timed out: stop exchanging, results are invalid
+
+    static constexpr int NW = BLOCK / WAVE;
+
+    __device__ __forceinline__ void init(void *ws) {
+        char *base = static_cast<char *>(ws);
+        WsHeader *hdr = reinterpret_cast<WsHeader *>(base);
+        slots = (gu64 *)(reinterpret_cast<unsigned long long *>(base + WS_XCHG_OFF));
+        status = &hdr->status;
+        // every workgroup reads the base before any workgroup can finish (finishing needs
+        // everybody's first publish), so the writer at the end never races this read
+        tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        step = 0;
+        nwg = (int)gridDim.x;
+        dead = false;
+    }
+
+    // Leaves base + steps in the workspace for the next launch (call from ONE thread, at the end).
+    __device__ __forceinline__ void finish(void *ws) {
+        WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+        __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // All threads call with their per-thread partials; all threads return the global result.
+    template <class OpA, class OpB>
+    __device__ __forceinline__ void allreduce2(double &a, double &b) {
+        __shared__ double part[2 * NW];
+        __shared__ double bc[2];
+        __shared__ int sh_dead;
+        const int lane = threadIdx.x & (WAVE - 1);
+        const int wave = threadIdx.x / WAVE;
+        a = wave_reduce<OpA>(a);
+        b = wave_reduce<OpB>(b);
+        if (lane == 0) { part[2 * wave] = a; part[2 * wave + 1] = b; }
+        __syncthreads();
+        if (wave == 0) {
+            double ta = lane < NW ? part[2 * lane] : OpA::ident();
+            double tb = lane < NW ? part[2 * lane + 1] : OpB::ident();
+            ta = wave_reduce<OpA>(ta);
+            tb = wave_reduce<OpB>(tb);
+            if (nwg > 1 && !dead) {
+                gu64 *buf = slots + (size_t)(step & 1) * MAX_COOP_WG * XCHG_GRANULES;
+                // publish: lanes 0..3 store one granule each (32 contiguous bytes)
+                if (lane < XCHG_GRANULES) {
+                    const unsigned long long bits =
+                        (unsigned long long)__double_as_longlong(lane < 2 ? ta : tb);
+                    const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+                    __hip_atomic_store(buf + (size_t)blockIdx.x * XCHG_GRANULES + lane,
+                                       ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // gather: lane l owns workgroups l, l+64, ...
+                double ga = OpA::ident(), gb = OpB::ident();
+                const unsigned long long t0 = wall_clock64();
+                bool timeout = false;
+                for (int w = lane; w < ((nwg + WAVE - 1) / WAVE) * WAVE; w += WAVE) {
+                    unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+                    const bool mine = w < nwg;
+                    gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG_GRANULES;
+                    for (;;) {
+                        bool ok = true;
+                        if (mine) {
+                            x0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            x1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            x2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            x3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag &&
+                                 (uint32_t)(x2 >> 32) == tag && (uint32_t)(x3 >> 32) == tag;
+                        }
+                        if (__all(ok)) break;
+                        if (wall_clock64() - t0 > SPIN_BOUND_TICKS) { timeout = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (timeout) break;
+                    if (mine) {
+                        const double va = __longlong_as_double(
+                            (long long)(((x1 & 0xFFFFFFFFull) << 32) | (x0 & 0xFFFFFFFFull)));
+                        const double vb = __longlong_as_double(
+                            (long long)(((x3 & 0xFFFFFFFFull) << 32) | (x2 & 0xFFFFFFFFull)));
+                        ga = OpA::apply(ga, va);
+                        gb = OpB::apply(gb, vb);
+                    }
+                }
+                ta = wave_reduce<OpA>(ga);
+                tb = wave_reduce<OpB>(gb);
+                if (timeout) {
+                    dead = true;
+                    if (lane == 0) atomicOr(status, RLVI_ST_TIMEOUT);
+                }
+            }
+            if (lane == 0) { bc[0] = ta; bc[1] = tb; sh_dead = dead ? 1 : 0; }
+        }
+        __syncthreads();
+        a = bc[0];
+        b = bc[1];
+        dead = sh_dead != 0;
+        ++step;
+        ++tag;
+    }
+};
+
+}  // namespace rlvi

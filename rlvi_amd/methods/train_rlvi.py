@@ -1,0 +1,74 @@
+"""MI355X drop-in for the reference's `--method=rlvi` plug-in.
+
+Same names, positional order, in-place mutation and return types as
+deep-learning/methods/train_rlvi.py (the boundary of SURVEY.md 8(b)):
+
+    train_rlvi(train_loader, model, optimizer, residuals, weights, overfit, threshold)
+        -> (train_acc: float, threshold)                         reference :52-106
+    update_sample_weights(residuals, weights, tol=1e-3, maxiter=40) -> None   reference :14-38
+    false_negative_criterion(weights, alpha=0.05) -> 0-dim tensor            reference :41-49
+
+Every tensor statement of the reference's hot loop runs in librlvi_gfx950.so; torch is used for
+the model, the optimizer and device memory only.  `deep-learning/main.py` picks this module up
+unchanged when `methods` resolves to this package.
+"""
+import torch
+
+from .. import ops
+
+__all__ = ['train_rlvi']
+
+DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+@torch.no_grad()
+def update_sample_weights(residuals, weights, tol=1e-3, maxiter=40):
+    """Optimize Bernoulli probabilities in place (reference :14-38).
+
+    residuals is min-shifted in place and weights overwritten, exactly as the reference does;
+    one cooperative HIP launch, no host synchronisation."""
+    ops.estep_deep(residuals.detach(), weights, tol=tol, maxiter=maxiter)
+
+
+@torch.no_grad()
+def false_negative_criterion(weights, alpha=0.05):
+    """Threshold from the fixed probability (alpha) of type II error (reference :41-49)."""
+    return ops.fn_threshold(weights, alpha=alpha)
+
+
+def train_rlvi(train_loader, model, optimizer,
+               residuals, weights, overfit, threshold):
+    """Train one epoch with Bernoulli-probability-weighted SGD updates (reference :52-106).
+
+    residuals, weights: caller-owned fp32 vectors of len(train_dataset) on DEVICE, mutated in
+    place.  Returns (train_acc, threshold); threshold comes back unchanged while `overfit` is
+    False and as a 0-dim device tensor once truncation has run (as in the reference)."""
+    train_total = 0
+    train_correct = torch.zeros((), dtype=torch.float32, device=weights.device)
+    out = torch.empty(4, dtype=torch.float32, device=weights.device)
+
+    for (images, labels, indexes) in train_loader:
+        images = images.to(weights.device, non_blocking=True)
+        labels = labels.to(weights.device, non_blocking=True)
+        indexes = indexes.to(weights.device, non_blocking=True)
+
+        logits = model(images)
+        # reference :85,:89-94 and the backward of :96 in one fused pass over the logits:
+        # top-1, per-sample CE, residuals[indexes] = loss, weights[indexes] gather, weighted
+        # mean and d(loss)/d(logits)
+        out, grad = ops.mstep_fwd_bwd(logits.detach(), labels, indexes, weights,
+                                      residuals.detach(), out=out)
+        train_total += 1
+        train_correct += out[1]
+
+        optimizer.zero_grad()
+        logits.backward(grad)          # == loss.backward() of the reference (:96)
+        optimizer.step()
+
+    update_sample_weights(residuals, weights)
+    if overfit:
+        # Regularization: truncate samples with high probability of corruption (:100-103)
+        threshold, _, _ = ops.threshold_truncate(weights, threshold)
+
+    train_acc = float(train_correct) / float(train_total)
+    return train_acc, threshold

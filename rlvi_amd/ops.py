@@ -1,0 +1,248 @@
+"""torch-facing wrappers of the C ABI (raw device pointers + current HIP stream).
+
+PyTorch is plumbing here: device memory, streams, autograd glue.  All arithmetic of the
+hot path happens in librlvi_gfx950.so; there is no eager/CPU fallback -- a missing library
+or a non-GPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.RlviError(
+                "rlvi_amd runs only on an MI355X HIP device: got a CPU tensor "
+                "(there is no CPU fallback; the CPU restatement under oracle/ is test-only)")
+
+
+class Workspace:
+    """Caller-owned scratch + control words (include/rlvi_hip.h, 'Conventions')."""
+
+    def __init__(self, device, max_n, max_b):
+        L = _lib.load()
+        self.max_n, self.max_b = int(max_n), int(max_b)
+        self.nbytes = int(L.rlvi_workspace_bytes(self.max_n, self.max_b))
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        assert self.buf.data_ptr() % 256 == 0
+        _lib.check(L.rlvi_workspace_init(_ptr(self.buf), self.nbytes, _stream_ptr()),
+                   "rlvi_workspace_init")
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr())
+
+    def status(self):
+        s = ctypes.c_int32(0)
+        _lib.check(_lib.load().rlvi_workspace_status(self.ptr, ctypes.byref(s), _stream_ptr()),
+                   "rlvi_workspace_status")
+        return s.value
+
+
+def workspace(device, n=0, b=0):
+    """Per (device, stream) workspace, grown on demand."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.max_n < n or ws.max_b < b:
+        ws = Workspace(device, max(n, ws.max_n if ws else 0, 1 << 16),
+                       max(b, ws.max_b if ws else 0, 1 << 16))
+        _workspaces[key] = ws
+    return ws
+
+
+def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_grad=True,
+                  out=None, grad=None):
+    """One mini-batch of the M-step (train_rlvi.py:85-96 without model/optimizer).
+
+    Scatters the per-sample NLL into `residuals[idx]`, gathers the lagged pi from
+    `weights[idx]`, returns (out, grad) with out = fp32[4] device tensor
+    {weighted mean loss, top-1 %, sum pi*l, hits} and grad = dL/dlogits (or None).
+    """
+    L = _lib.load()
+    _require_gpu(logits, labels, idx, weights, residuals)
+    if logits.dim() != 2:
+        raise ValueError("logits must be [B, C]")
+    B, C = logits.shape
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    if labels.dtype != torch.int64 or not labels.is_contiguous():
+        labels = labels.to(torch.int64).contiguous()
+    if idx is not None and (idx.dtype != torch.int64 or not idx.is_contiguous()):
+        idx = idx.to(torch.int64).contiguous()
+    if weights.dtype != torch.float32 or not weights.is_contiguous():
+        raise ValueError("weights must be a contiguous fp32 vector (it is read in place)")
+    if residuals is not None and (residuals.dtype != torch.float32 or not residuals.is_contiguous()):
+        raise ValueError("residuals must be a contiguous fp32 vector (it is written in place)")
+    N = weights.shape[0]
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    if want_grad and grad is None:
+        grad = torch.empty((B, C), dtype=logits.dtype, device=logits.device)
+    if not want_grad:
+        grad = None
+    ws = workspace(logits.device, N, B)
+    fn = L.rlvi_mstep_fwd_bwd_f32 if logits.dtype == torch.float32 else L.rlvi_mstep_fwd_bwd_bf16
+    rc = fn(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(idx), _ptr(weights),
+            _ptr(residuals), N, B, C, float(inv_scale if inv_scale is not None else 1.0 / B),
+            _ptr(grad), grad.stride(0) if grad is not None else 0, _ptr(out), ws.ptr,
+            _stream_ptr())
+    _lib.check(rc, "rlvi_mstep_fwd_bwd")
+    return out, grad
+
+
+def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None):
+    """update_sample_weights (train_rlvi.py:14-38), in place on both vectors."""
+    L = _lib.load()
+    _require_gpu(residuals, weights)
+    for t in (residuals, weights):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1:
+            raise ValueError("residuals / weights must be contiguous 1-D fp32 tensors")
+    if residuals.shape != weights.shape:
+        raise ValueError("residuals and weights differ in length")
+    N = weights.shape[0]
+    ws = workspace(weights.device, N, 0)
+    rc = L.rlvi_estep_deep_f32(_ptr(residuals), _ptr(weights), N, float(tol), int(maxiter),
+                               _ptr(iters), _ptr(trace), ws.ptr, _stream_ptr())
+    _lib.check(rc, "rlvi_estep_deep_f32")
+
+
+def fn_threshold(weights, alpha=0.05):
+    """false_negative_criterion (train_rlvi.py:41-49) -> 0-dim fp32 device tensor."""
+    L = _lib.load()
+    _require_gpu(weights)
+    w = weights if (weights.dtype == torch.float32 and weights.is_contiguous()) \
+        else weights.float().contiguous()
+    thr = torch.empty(1, dtype=torch.float32, device=w.device)
+    ws = workspace(w.device, w.shape[0], 0)
+    _lib.check(L.rlvi_fn_threshold_f32(_ptr(w), w.shape[0], float(alpha), _ptr(thr), ws.ptr,
+                                       _stream_ptr()), "rlvi_fn_threshold_f32")
+    return thr.reshape(())
+
+
+def threshold_truncate(weights, threshold, alpha=0.05, want_mask=False):
+    """train_rlvi.py:102-103: threshold = max(threshold, criterion); weights[weights<thr] = 0.
+
+    Returns (threshold 0-dim tensor, mask bool tensor or None, kept int64 0-dim tensor)."""
+    L = _lib.load()
+    _require_gpu(weights)
+    if weights.dtype != torch.float32 or not weights.is_contiguous():
+        raise ValueError("weights must be a contiguous fp32 vector (it is truncated in place)")
+    N = weights.shape[0]
+    thr = torch.as_tensor(threshold, dtype=torch.float32, device=weights.device).reshape(1).clone()
+    mask = torch.empty(N, dtype=torch.uint8, device=weights.device) if want_mask else None
+    kept = torch.zeros(1, dtype=torch.int64, device=weights.device)
+    ws = workspace(weights.device, N, 0)
+    _lib.check(L.rlvi_threshold_truncate_f32(_ptr(weights), N, float(alpha), _ptr(thr), _ptr(mask),
+                                             _ptr(kept), ws.ptr, _stream_ptr()),
+               "rlvi_threshold_truncate_f32")
+    return thr.reshape(()), (mask.bool() if want_mask else None), kept.reshape(())
+
+
+def fused_em(logits, labels, pi, tol=1e-3, maxiter=40, inv_scale=None, want_grad=True):
+    """In-batch E+M (online order): NLL -> E-step on this batch -> weighted loss + grad.
+
+    `pi` [B] fp32 is read (first error only) and overwritten with the new posteriors.
+    Returns (out[4], grad, loss_rows (min-shifted NLL), iters int32 tensor)."""
+    L = _lib.load()
+    _require_gpu(logits, labels, pi)
+    if logits.dtype != torch.float32:
+        logits = logits.float()
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    labels = labels.to(torch.int64).contiguous()
+    B, C = logits.shape
+    out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    grad = torch.empty((B, C), dtype=torch.float32, device=logits.device) if want_grad else None
+    rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    iters = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    ws = workspace(logits.device, B, B)
+    rc = L.rlvi_fused_em_f32(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(rows), _ptr(pi),
+                             B, C, float(inv_scale if inv_scale is not None else 1.0 / B),
+                             float(tol), int(maxiter), _ptr(grad),
+                             grad.stride(0) if grad is not None else 0, _ptr(out), _ptr(iters),
+                             ws.ptr, _stream_ptr())
+    _lib.check(rc, "rlvi_fused_em_f32")
+    return out, grad, rows, iters
+
+
+def update_weights_f64(losses, tol=1e-3, maxiter=100, online=False):
+    """standard-learning/rlvi.py:8-20 (online=False) or online-learning/main.py:45-58."""
+    L = _lib.load()
+    _require_gpu(losses)
+    l = losses.to(torch.float64).contiguous()
+    out = torch.empty_like(l)
+    iters = torch.zeros(1, dtype=torch.int32, device=l.device)
+    ws = workspace(l.device, l.shape[0], 0)
+    fn = L.rlvi_update_weights_online_f64 if online else L.rlvi_update_weights_f64
+    _lib.check(fn(_ptr(l), l.shape[0], float(tol), int(maxiter), _ptr(out), _ptr(iters), ws.ptr,
+                  _stream_ptr()), "rlvi_update_weights_f64")
+    return out, iters
+
+
+def linreg_losses(X, y, theta, w):
+    """rlvi.py:72-74: losses = 0.5 (y - X theta)^2 / sigma2, sigma2 = w.r / sum(w)."""
+    L = _lib.load()
+    _require_gpu(X, y, theta, w)
+    X = X.to(torch.float64).contiguous()
+    n, d = X.shape
+    losses = torch.empty(n, dtype=torch.float64, device=X.device)
+    s2 = torch.empty(1, dtype=torch.float64, device=X.device)
+    ws = workspace(X.device, n, 0)
+    _lib.check(L.rlvi_linreg_losses_f64(_ptr(X), _ptr(y.to(torch.float64).contiguous()),
+                                        _ptr(theta.to(torch.float64).contiguous()),
+                                        _ptr(w.to(torch.float64).contiguous()), n, d,
+                                        _ptr(losses), _ptr(s2), ws.ptr, _stream_ptr()),
+               "rlvi_linreg_losses_f64")
+    return losses, s2.reshape(())
+
+
+def logistic_nll(X, w, b):
+    """online-learning/main.py:295-296,:84-85: -log sigmoid(X w + b)."""
+    L = _lib.load()
+    _require_gpu(X, w)
+    X = X.to(torch.float64).contiguous()
+    n, d = X.shape
+    losses = torch.empty(n, dtype=torch.float64, device=X.device)
+    _lib.check(L.rlvi_logistic_nll_f64(_ptr(X), _ptr(w.to(torch.float64).contiguous()), float(b),
+                                       n, d, _ptr(losses), _stream_ptr()),
+               "rlvi_logistic_nll_f64")
+    return losses
+
+
+class _WeightedCE(torch.autograd.Function):
+    """loss = mean_i(pi[idx_i] * CE(logits_i, y_i)) with the residual scatter as a side effect
+    (train_rlvi.py:89-94); backward hands out the gradient the fused kernel already wrote."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, idx, weights, residuals, inv_scale):
+        out, grad = mstep_fwd_bwd(logits.detach(), labels, idx, weights, residuals, inv_scale)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss.to(grad.dtype), None, None, None, None, None
+
+
+def weighted_cross_entropy(logits, labels, idx, weights, residuals, inv_scale=None):
+    """Autograd entry: returns (loss 0-dim tensor, out[4])."""
+    return _WeightedCE.apply(logits, labels, idx, weights, residuals, inv_scale)

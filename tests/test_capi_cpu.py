@@ -1,0 +1,107 @@
+"""CPU-side checks of the C-ABI library and the host logic (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rlvi_amd import _build, _lib
+    _build.build()
+    return _lib.load()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rlvi_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rlvi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from rlvi_amd import _lib
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rlvi_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names      # the ctypes table covers the whole header
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.rlvi_abi_version() == 1
+    assert lib.rlvi_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert lib.rlvi_error_string(code) not in (b"ok", b"unknown rlvi error")
+
+
+def test_workspace_bytes_monotone(lib):
+    a = lib.rlvi_workspace_bytes(0, 0)
+    b = lib.rlvi_workspace_bytes(65536, 65536)
+    c = lib.rlvi_workspace_bytes(1 << 20, 65536)
+    assert 0 < a <= b <= c and a % 256 == 0 and c % 256 == 0
+
+
+def test_argument_errors_without_a_gpu(lib):
+    """Argument validation happens on the host before any launch."""
+    assert lib.rlvi_estep_deep_f32(None, None, 10, 1e-3, 40, None, None, None, None) == -1
+    assert lib.rlvi_fn_threshold_f32(None, 10, 0.05, None, None, None) == -1
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p = (p + 255) & ~255
+    assert lib.rlvi_estep_deep_f32(p, p, 0, 1e-3, 40, None, None, p, None) == -2
+    assert lib.rlvi_estep_deep_f32(p, p, -5, 1e-3, 40, None, None, p, None) == -2
+    assert lib.rlvi_estep_deep_f32(p, p + 2, 8, 1e-3, 40, None, None, p, None) == -3
+    assert lib.rlvi_mstep_fwd_bwd_f32(p, 4, p, p, p, p, 8, 8, 10, 0.1, None, 0, p, p, None) == -2  # ld < C
+    assert lib.rlvi_update_weights_f64(p, 0, 1e-3, 10, p, None, p, None) == -2
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from rlvi_amd import _lib, ops
+    z = torch.zeros(4, 10)
+    with pytest.raises(_lib.RlviError, match="no CPU fallback"):
+        ops.mstep_fwd_bwd(z, torch.zeros(4, dtype=torch.int64), torch.arange(4), torch.ones(4),
+                          torch.zeros(4))
+    with pytest.raises(_lib.RlviError):
+        ops.estep_deep(torch.zeros(4), torch.ones(4))
+    with pytest.raises(_lib.RlviError):
+        ops.fn_threshold(torch.ones(4))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from rlvi_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.RlviError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under rlvi_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rlvi_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "rlvi_oracle" not in txt, f
+
+
+def test_plugin_interface_matches_reference_names():
+    import inspect
+    from rlvi_amd import methods
+    from rlvi_amd.methods import train_rlvi as mod_fn
+    import rlvi_amd.methods.train_rlvi  # noqa: F401
+    import sys
+    m = sys.modules["rlvi_amd.methods.train_rlvi"]
+    assert m.__all__ == ['train_rlvi']
+    assert list(inspect.signature(m.train_rlvi).parameters) == [
+        "train_loader", "model", "optimizer", "residuals", "weights", "overfit", "threshold"]
+    sig = inspect.signature(m.update_sample_weights)
+    assert list(sig.parameters) == ["residuals", "weights", "tol", "maxiter"]
+    assert sig.parameters["tol"].default == 1e-3 and sig.parameters["maxiter"].default == 40
+    sig = inspect.signature(m.false_negative_criterion)
+    assert list(sig.parameters) == ["weights", "alpha"] and sig.parameters["alpha"].default == 0.05
+    assert methods.train_rlvi is mod_fn

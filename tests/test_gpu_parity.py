@@ -1,0 +1,395 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every check goes through the C ABI
+(librlvi_gfx950.so via rlvi_amd.ops) and compares with (i) the committed golden vectors
+produced by the reference itself and (ii) the CPU oracle on the same seeded inputs.
+
+Bars: selection mask bit-exact; pi, NLL and weighted loss within 1e-5 relative; E-step
+iteration count equal; gradient within 1e-5 relative Frobenius + 1e-6 max-abs.
+"""
+import numpy as np
+import pytest
+
+from rlvi_amd import synth
+from test_oracle_golden import (REL, check_mstep_against_golden, g1_cases, g1_inputs, g3_cases,
+                                g3_inputs, rel_pi)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from rlvi_amd import _lib, ops
+    _lib.load()                      # fails loudly if the HIP library is missing
+    return torch, ops, torch.device("cuda:0")
+
+
+def dev_status(ops, dev):
+    return ops.workspace(dev).status()
+
+
+def run_mstep(gpu, d, dtype="f32", want_grad=True):
+    torch, ops, dev = gpu
+    z = torch.from_numpy(d["logits"]).to(dev)
+    if dtype == "bf16":
+        z = z.to(torch.bfloat16)
+    res = torch.from_numpy(d["residuals"].copy()).to(dev)
+    out, grad = ops.mstep_fwd_bwd(z, torch.from_numpy(d["labels"]).to(dev),
+                                  torch.from_numpy(d["idx"]).to(dev),
+                                  torch.from_numpy(d["weights"]).to(dev), res,
+                                  want_grad=want_grad)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    return dict(loss=o[0], prec1=o[1], sum_pil=o[2], hits=o[3],
+                grad=None if grad is None else grad.float().cpu().numpy()), res.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------ M-step
+@pytest.mark.parametrize("key", g3_cases())
+def test_mstep_golden(key, golden, gpu):
+    g = golden("g3_mstep")
+    d, B, C = g3_inputs(g, key)
+    if str(g[key + "/dtype"]) == "bf16":
+        pytest.skip("bf16-rounded inputs are covered by test_mstep_bf16_golden")
+    out, res = run_mstep(gpu, d)
+    out["loss_rows"] = res[d["idx"]]
+    check_mstep_against_golden(g, key, out, res, d["logits"])
+    assert dev_status(gpu[1], gpu[2]) == 0
+
+
+@pytest.mark.parametrize("key", [k for k in g3_cases() if k.endswith("bf16")])
+def test_mstep_bf16_golden(key, golden, gpu):
+    """bf16 logits in HBM, fp32 arithmetic: the target is the reference fed the bf16-rounded
+    logits as fp32.  NLL/loss/top-1 keep the fp32 bars; the gradient is compared
+    after the same bf16 rounding of the reference gradient (output storage precision)."""
+    torch, ops, dev = gpu
+    g = golden("g3_mstep")
+    d, B, C = g3_inputs(g, key)
+    out, res = run_mstep(gpu, d, dtype="bf16")
+    np.testing.assert_allclose(res[d["idx"]], g[key + "/loss_rows"], rtol=REL, atol=1e-6)
+    assert abs(float(out["loss"]) - float(g[key + "/loss"])) <= REL * abs(float(g[key + "/loss"]))
+    step = int(g[key + "/grad_rowstep"])
+    ref = torch.from_numpy(g[key + "/grad_rows"]).to(torch.bfloat16).float().numpy()
+    got = out["grad"][::step]
+    # one bf16 ulp (2^-8 relative) where the rounding boundary is straddled; 1e-7 absolute for
+    # the cancelling label entry (p-1)*g of confident rows (the fp32 bar is 1e-6 max-abs)
+    np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,C", [(1, 1), (1, 2), (3, 3), (7, 5), (65, 7), (129, 10), (1000, 33),
+                                 (257, 100), (513, 101), (300, 256), (130, 260), (70, 1000),
+                                 (33, 2048)])
+def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
+    """Ragged batches and every (vector width, lane group, chunks) dispatch of the kernel."""
+    d = synth.mstep_inputs(B, C, N=B + 17, seed=B * 7 + C, zero_frac=0.1)
+    out, res = run_mstep(gpu, d)
+    r0 = d["residuals"].copy()
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], r0)
+    np.testing.assert_allclose(res, r0, rtol=REL, atol=1e-6)
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= REL * max(abs(float(ref["loss"])), 1e-6)
+    assert float(out["prec1"]) == pytest.approx(float(ref["prec1"]), abs=1e-4)
+    diff = out["grad"].astype(np.float64) - ref["grad"]
+    assert np.sqrt((diff ** 2).sum()) <= REL * max(np.sqrt((ref["grad"].astype(np.float64) ** 2).sum()), 1e-12)
+    assert np.abs(diff).max() <= 1e-6
+    assert dev_status(gpu[1], gpu[2]) == 0
+
+
+def test_mstep_strided_rows_and_forward_only(gpu, oracle):
+    torch, ops, dev = gpu
+    B, C, LD = 96, 100, 128
+    d = synth.mstep_inputs(B, C, seed=11)
+    big = torch.zeros(B, LD, device=dev)
+    big[:, :C] = torch.from_numpy(d["logits"]).to(dev)
+    res = torch.zeros(B, device=dev)
+    out, grad = ops.mstep_fwd_bwd(big[:, :C], torch.from_numpy(d["labels"]).to(dev),
+                                  torch.from_numpy(d["idx"]).to(dev),
+                                  torch.from_numpy(d["weights"]).to(dev), res)
+    out2, none = ops.mstep_fwd_bwd(big[:, :C], torch.from_numpy(d["labels"]).to(dev),
+                                   torch.from_numpy(d["idx"]).to(dev),
+                                   torch.from_numpy(d["weights"]).to(dev), res, want_grad=False)
+    r0 = d["residuals"].copy()
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], r0)
+    assert none is None
+    assert torch.equal(out, out2)
+    assert abs(float(out[0]) - float(ref["loss"])) <= REL * abs(float(ref["loss"]))
+    diff = grad.cpu().numpy().astype(np.float64) - ref["grad"]
+    assert np.abs(diff).max() <= 1e-6
+
+
+def test_mstep_out_of_range_sets_status_and_touches_nothing(gpu):
+    torch, ops, dev = gpu
+    B, C = 64, 10
+    d = synth.mstep_inputs(B, C, seed=3)
+    lab = d["labels"].copy()
+    lab[5] = C + 3
+    idx = d["idx"].copy()
+    idx[9] = B + 100
+    res = torch.full((B,), -1.0, device=dev)
+    ws = ops.workspace(dev)
+    assert ws.status() == 0
+    out, grad = ops.mstep_fwd_bwd(torch.from_numpy(d["logits"]).to(dev), torch.from_numpy(lab).to(dev),
+                                  torch.from_numpy(idx).to(dev),
+                                  torch.from_numpy(d["weights"]).to(dev), res)
+    torch.cuda.synchronize()
+    assert ws.status() & 1
+    r = res.cpu().numpy()
+    assert r[d["idx"][5]] == -1.0          # bad rows scatter nothing
+    assert np.isfinite(float(out[0]))
+    # clear the sticky status for the tests that follow
+    from rlvi_amd import _lib
+    import ctypes
+    _lib.check(_lib.load().rlvi_workspace_init(ws.ptr, ws.nbytes, None), "init")
+    torch.cuda.synchronize()
+    assert ws.status() == 0
+
+
+def test_mstep_bench_size_properties_and_oracle(gpu, oracle):
+    """65 536 x 100 (BASELINE.json headline shape): oracle comparison plus size-independent
+    properties: gradient rows sum to ~0, scalars consistent with the scattered residuals,
+    run-to-run bit-identical (fixed reduction order)."""
+    torch, ops, dev = gpu
+    B, C = 65536, 100
+    d = synth.mstep_inputs(B, C)
+    out, res = run_mstep(gpu, d)
+    out_b, res_b = run_mstep(gpu, d)
+    assert np.array_equal(res, res_b) and np.array_equal(out["grad"], out_b["grad"])
+    assert out["loss"] == out_b["loss"] and out["hits"] == out_b["hits"]
+    g = out["grad"].astype(np.float64)
+    assert np.abs(g.sum(1)).max() <= 2e-6 / 1.0
+    pil = (res[d["idx"]].astype(np.float64) * d["weights"][d["idx"]].astype(np.float64)).sum()
+    assert abs(float(out["sum_pil"]) - pil) <= REL * pil
+    assert abs(float(out["loss"]) - pil / B) <= REL * pil / B
+    r0 = d["residuals"].copy()
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], r0)
+    np.testing.assert_allclose(res, r0, rtol=REL, atol=1e-6)
+    assert float(out["hits"]) == float(ref["prec1"]) * B / 100.0
+    diff = g - ref["grad"]
+    assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+
+
+# ------------------------------------------------------------------------------ E-step
+@pytest.mark.parametrize("key", g1_cases())
+def test_estep_threshold_mask_golden(key, golden, gpu, oracle):
+    torch, ops, dev = gpu
+    g = golden("g1_g2_estep_threshold")
+    r, w, N = g1_inputs(g, key, oracle)
+    maxiter = 40
+    rt = torch.from_numpy(r).to(dev)
+    wt = torch.from_numpy(w).to(dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    trace = torch.zeros(2 * maxiter, device=dev)
+    ops.estep_deep(rt, wt, iters=iters, trace=trace)
+    torch.cuda.synchronize()
+    it = int(iters.item())
+    assert it == int(g[key + "/iters"])
+    tr = trace.cpu().numpy()
+    np.testing.assert_allclose(tr[0:2 * it:2], g[key + "/errs"], rtol=2e-5, atol=1e-6)
+    wo = wt.cpu().numpy()
+    sl = slice(None, None, int(g["stride"])) if N > 4096 else slice(None)
+    rel, small = rel_pi(wo[sl], g[key + "/w_out"])
+    assert rel <= REL and small <= 1e-7
+    assert np.array_equal(rt.cpu().numpy()[sl], g[key + "/res_out"])     # min-shift is exact
+    # threshold + truncation + mask through the fused kernel
+    thr, mask, kept = ops.threshold_truncate(wt, 0, want_mask=True)
+    torch.cuda.synchronize()
+    assert abs(float(thr) - float(g[key + "/thr"])) <= REL * max(float(g[key + "/thr"]), 1e-30)
+    assert int(kept) == int(g[key + "/kept"])
+    assert np.array_equal(np.packbits(mask.cpu().numpy()), g[key + "/mask_bits"])   # bit-exact
+    wsum = wt.cpu().numpy().astype(np.float64).sum()
+    assert abs(wsum - float(g[key + "/w_trunc_sum"])) <= REL * max(1.0, float(g[key + "/w_trunc_sum"]))
+    assert dev_status(ops, dev) == 0
+
+
+def test_threshold_handmade_and_standalone(golden, gpu):
+    torch, ops, dev = gpu
+    g = golden("g1_g2_estep_threshold")
+    from rlvi_amd.methods import false_negative_criterion
+    for k in g["extra"]:
+        w = torch.from_numpy(g[f"x_{k}/w"].copy()).to(dev)
+        thr0 = false_negative_criterion(w)
+        assert thr0.dim() == 0 and float(thr0) == float(g[f"x_{k}/thr"]), k
+        thr, mask, kept = ops.threshold_truncate(w, 0, want_mask=True)
+        assert float(thr) == float(g[f"x_{k}/thr"]), k
+        assert np.array_equal(w.cpu().numpy(), g[f"x_{k}/w_trunc"]), k
+        assert np.array_equal(np.packbits(mask.cpu().numpy()), g[f"x_{k}/mask_bits"]), k
+        assert int(kept) == int(g[f"x_{k}/kept"]), k
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 1023, 1025, 4097, 16385, 70001, 100003, 300000])
+def test_threshold_vs_oracle_sizes(N, gpu, oracle):
+    """All three key-storage paths (registers 16 / 80 per thread, streaming) + monotone max."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(N)
+    w = rng.random(N).astype(np.float32)
+    w[rng.random(N) < 0.2] = 1.0
+    w[rng.random(N) < 0.1] = 0.0
+    thr_ref, li, beta = oracle.false_negative_criterion(w, full=True)
+    wt = torch.from_numpy(w.copy()).to(dev)
+    thr = ops.fn_threshold(wt)
+    assert float(thr) == float(thr_ref)
+    prev = float(thr_ref) + 0.01 if N % 2 else 0.0
+    thr2, mask, kept = ops.threshold_truncate(wt, prev, want_mask=True)
+    expect = max(np.float32(prev), thr_ref)
+    assert float(thr2) == float(expect)
+    w2 = w.copy()
+    m_ref = oracle.truncate(w2, expect)
+    assert np.array_equal(wt.cpu().numpy(), w2)
+    assert np.array_equal(mask.cpu().numpy(), m_ref)
+    assert int(kept) == int(m_ref.sum())
+
+
+@pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 50000, 65536, 75750, 200000, 600000])
+def test_estep_vs_oracle_sizes(N, gpu, oracle):
+    """Single-workgroup and cooperative multi-workgroup paths; deterministic across runs."""
+    torch, ops, dev = gpu
+    r = synth.residual_vector("bimodal", N, seed=N)
+    w0 = np.random.default_rng(N).random(N).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        rt, wt = torch.from_numpy(r.copy()).to(dev), torch.from_numpy(w0.copy()).to(dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=iters)
+        torch.cuda.synchronize()
+        outs.append((rt.cpu().numpy(), wt.cpu().numpy(), int(iters)))
+    assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    rr, ww = r.copy(), w0.copy()
+    it, err, avg = oracle.update_sample_weights(rr, ww, trace=True)
+    tie = np.min(np.abs(err - 1e-3)) < 1e-5 * 1e-3      # stop decision within rounding of tol
+    if not tie:
+        assert outs[0][2] == it
+        rel, small = rel_pi(outs[0][1], ww)
+        assert rel <= REL and small <= 1e-7
+    assert np.array_equal(outs[0][0], rr)
+    assert dev_status(ops, dev) == 0
+
+
+def test_estep_maxiter_cap_and_tol(gpu, oracle):
+    torch, ops, dev = gpu
+    N = 5000
+    r = synth.residual_vector("exp", N, seed=1)
+    for (tol, maxiter) in ((1e-3, 3), (1e-9, 40), (10.0, 40), (1e-3, 0)):
+        rr, ww = r.copy(), np.ones(N, np.float32)
+        it = oracle.update_sample_weights(rr, ww, tol=tol, maxiter=maxiter)
+        rt, wt = torch.from_numpy(r.copy()).to(dev), torch.ones(N, device=dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, tol=tol, maxiter=maxiter, iters=iters)
+        assert int(iters) == it
+        rel, small = rel_pi(wt.cpu().numpy(), ww)
+        assert rel <= REL and small <= 1e-7
+
+
+# ------------------------------------------------------------------------------ fused E+M
+@pytest.mark.parametrize("B,C", [(256, 10), (4096, 10), (1000, 100), (65536, 100)])
+def test_fused_em_matches_composition(B, C, gpu, oracle):
+    """In-batch E+M == a1 -> a7 -> a4/a5 composed from the oracle's pieces."""
+    torch, ops, dev = gpu
+    d = synth.mstep_inputs(B, C, seed=B + C)
+    pi0 = np.ones(B, np.float32)
+    pit = torch.from_numpy(pi0.copy()).to(dev)
+    out, grad, rows, iters = ops.fused_em(torch.from_numpy(d["logits"]).to(dev),
+                                          torch.from_numpy(d["labels"]).to(dev), pit)
+    torch.cuda.synchronize()
+    loss, _ = oracle.nll_rows(d["logits"], d["labels"])
+    l2, w2 = loss.copy(), pi0.copy()
+    it = oracle.update_sample_weights(l2, w2)
+    ref = oracle.mstep(d["logits"], d["labels"], np.arange(B), w2, np.zeros(B, np.float32))
+    assert int(iters) == it
+    rel, small = rel_pi(pit.cpu().numpy(), w2)
+    assert rel <= REL and small <= 1e-7
+    np.testing.assert_allclose(rows.cpu().numpy(), l2, rtol=REL, atol=1e-6)
+    assert abs(float(out[0]) - float(ref["loss"])) <= 2 * REL * abs(float(ref["loss"]))
+    diff = grad.cpu().numpy().astype(np.float64) - ref["grad"]
+    assert np.sqrt((diff ** 2).sum()) <= 2 * REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+
+
+# ------------------------------------------------------------------------------ fp64 paths
+def test_update_weights_f64_golden(golden, gpu):
+    torch, ops, dev = gpu
+    g = golden("g5_standard")
+    for n in (40, 1000):
+        for kind in ("exp", "bimodal", "heavy"):
+            k = f"uw_{kind}_{n}"
+            w, it = ops.update_weights_f64(torch.from_numpy(g[k + "/losses"]).to(dev))
+            assert int(it) == len(g[k + "/errs"])
+            np.testing.assert_allclose(w.cpu().numpy(), g[k + "/w"], rtol=1e-11, atol=1e-300)
+    g = golden("g6_online")
+    keys = [f"uw_{kind}_{B}" for B in (100, 256) for kind in ("exp", "bimodal", "heavy")] + ["uw_first"]
+    for k in keys:
+        w, _ = ops.update_weights_f64(torch.from_numpy(g[k + "/losses"]).to(dev), online=True)
+        np.testing.assert_allclose(w.cpu().numpy(), g[k + "/w"], rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("n", [3, 5000, 20000, 100000])
+def test_update_weights_f64_vs_oracle(n, gpu, oracle):
+    torch, ops, dev = gpu
+    l = synth.residual_vector("bimodal", n, seed=n).astype(np.float64)
+    for online in (False, True):
+        ref, it = (oracle.update_weights_rlvi if online else oracle.update_weights)(l, trace=True)[:2]
+        w, its = ops.update_weights_f64(torch.from_numpy(l).to(dev), online=online)
+        assert int(its) == it
+        np.testing.assert_allclose(w.cpu().numpy(), ref, rtol=1e-10, atol=1e-300)
+
+
+def test_linreg_and_logistic_nll(gpu, oracle):
+    torch, ops, dev = gpu
+    X, y = synth.linreg_data(1000, 20, seed=0)
+    rng = np.random.default_rng(1)
+    theta = 1 + 0.1 * rng.standard_normal(20)
+    w = rng.random(1000)
+    ref, s2 = oracle.linreg_losses(X, y, theta, w)
+    got, s2g = ops.linreg_losses(*(torch.from_numpy(a).to(dev) for a in (X, y, theta, w)))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-11)
+    assert float(s2g) == pytest.approx(s2, rel=1e-12)
+    Xl, wl, b = synth.logistic_data(256, 60)
+    ref = oracle.logistic_nll(Xl, wl, b)
+    got = ops.logistic_nll(torch.from_numpy(Xl).to(dev), torch.from_numpy(wl).to(dev), b)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-15)
+
+
+# ------------------------------------------------------------------------------ whole epochs
+def test_train_rlvi_epochs_golden(golden, gpu):
+    """G4: the drop-in train_rlvi on the GPU against four reference epochs (overfit F,F,T,T)."""
+    torch, ops, dev = gpu
+    from rlvi_amd.methods import train_rlvi
+    g = golden("g4_epoch")
+    X, y = torch.from_numpy(g["X"]), torch.from_numpy(g["y"])
+    N, B = int(g["N"]), int(g["B"])
+    model = torch.nn.Linear(X.shape[1], 10)
+    with torch.no_grad():
+        model.weight.copy_(torch.from_numpy(g["W0"]))
+        model.bias.copy_(torch.from_numpy(g["b0"]))
+    model.to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=float(g["lr"]), momentum=float(g["momentum"]))
+    residuals = torch.zeros(N, device=dev)
+    weights = torch.ones(N, device=dev)
+    threshold = 0
+    for ep in range(4):
+        perm = g["orders"][ep]
+        loader = [(X[perm[s:s + B]], y[perm[s:s + B]], torch.from_numpy(perm[s:s + B].astype(np.int64)))
+                  for s in range(0, N, B)]
+        model.train()
+        acc, threshold = train_rlvi(loader, model, opt, residuals, weights,
+                                    bool(g[f"ep{ep}/overfit"]), threshold)
+        assert isinstance(acc, float)
+        np.testing.assert_allclose(model.weight.detach().cpu().numpy(), g[f"ep{ep}/W"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(residuals.cpu().numpy(), g[f"ep{ep}/residuals"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(weights.cpu().numpy(), g[f"ep{ep}/weights"], rtol=2e-3, atol=2e-4)
+        assert float(threshold) == pytest.approx(float(g[f"ep{ep}/threshold"]), rel=2e-3, abs=1e-6)
+        assert acc == pytest.approx(float(g[f"ep{ep}/train_acc"]), abs=1e-3)
+    assert torch.is_tensor(threshold) and threshold.dim() == 0
+
+
+def test_weighted_ce_autograd(gpu, oracle):
+    torch, ops, dev = gpu
+    B, C = 200, 10
+    d = synth.mstep_inputs(B, C, seed=2)
+    z = torch.from_numpy(d["logits"]).to(dev).requires_grad_(True)
+    res = torch.zeros(B, device=dev)
+    loss, out = ops.weighted_cross_entropy(z, torch.from_numpy(d["labels"]).to(dev),
+                                           torch.from_numpy(d["idx"]).to(dev),
+                                           torch.from_numpy(d["weights"]).to(dev), res)
+    (2.0 * loss).backward()
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], d["residuals"].copy())
+    assert abs(float(loss) - float(ref["loss"])) <= REL * abs(float(ref["loss"]))
+    np.testing.assert_allclose(z.grad.cpu().numpy(), 2.0 * ref["grad"], rtol=1e-4, atol=2e-6)
