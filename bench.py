@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- RLVI samples/sec (fused E+M step) on synthetic logits 65 536 x 100 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch, with BOTH halves inside the timed region:
+  M  rlvi_mstep_fwd_bwd_f32   per-sample NLL, top-1, residual scatter, lagged-pi gather,
+                              pi-weighted loss and dL/dlogits in one streaming pass
+                              (reference train_rlvi.py:85-96 without the model)
+  E  rlvi_estep_deep_f32      the fixed point over all N samples (train_rlvi.py:14-38 / :99)
+i.e. exactly one `train_rlvi` epoch of a one-batch loader, model excluded.  The next step's M
+uses this step's pi (lagged pi, as in the reference).  With N ranks every rank streams its own
+65 536 rows (weak scaling), the NLL shards are all-gathered (RCCL) and every rank runs the E-step
+on the 65 536*N-sample vector (rlvi_amd/dist.py).
+
+Inputs are resident in HBM before the timed region; 12 (logits, grad) buffer pairs rotate so that
+> 256 MiB is touched between two uses of a line (HBM-cold, not Infinity-Cache-warm).  The K steps
+are captured into one hipGraph so the measurement is not host-launch-bound; timing is HIP events
+on the launch stream, bracketed by barrier + synchronize, MAX over ranks.
+
+Extra objects on the JSON line: `roofline` (the streaming M-step kernel, algorithmic bytes
+2*C*4+24 per sample against 8 TB/s), `cpu_baseline` (the CPU oracle timed on this box's host
+cores), `parts` (per-kernel times), `parity` (this run's outputs checked against the oracle).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+ROTATE = 12                # (logits, grad) pairs: 12 * 52.4 MB = 629 MB > 256 MiB Infinity Cache
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--rows", type=int, default=65536, help="rows per GPU")
+    ap.add_argument("--classes", type=int, default=100)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--profile-only", action="store_true",
+                    help="warmup + timed steps only (for rocprofv3 runs)")
+    return ap.parse_args()
+
+
+def make_inputs(torch, dev, B, C, N, rank):
+    """Recipe of SURVEY 8(d): set 0 is the seeded numpy recipe (used for the parity gate); the
+    other rotating sets are the same recipe drawn on the device."""
+    import numpy as np
+    from rlvi_amd import synth
+    d = synth.mstep_inputs(B, C, N=B, seed=synth.BENCH_SEED + rank)
+    labels = torch.from_numpy(d["labels"]).to(dev)
+    idx_local = torch.from_numpy(d["idx"]).to(dev) + rank * B       # owner-contiguous slices
+    logits = [torch.from_numpy(d["logits"]).to(dev)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(synth.BENCH_SEED + 1000 * rank)
+    clean = torch.from_numpy(np.random.default_rng(1 + rank).random(B) < 0.55).to(dev)
+    rows = torch.arange(B, device=dev)
+    for _ in range(ROTATE - 1):
+        z = 3.0 * torch.randn((B, C), generator=gen, device=dev, dtype=torch.float32)
+        z[rows[clean], labels[clean]] += 12.0
+        logits.append(z)
+    grads = [torch.empty((B, C), dtype=torch.float32, device=dev) for _ in range(ROTATE)]
+    wrng = np.random.default_rng(synth.BENCH_SEED)           # same on every rank: replicated pi
+    weights = torch.from_numpy(wrng.random(N).astype(np.float32)).to(dev)
+    residuals = torch.zeros(N, dtype=torch.float32, device=dev)
+    return d, labels, idx_local, logits, grads, weights, residuals
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rlvi_amd import dist as rdist
+    from rlvi_amd import ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    if a.gpus != world and rank == 0:
+        print(f"# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    B, C = a.rows, a.classes
+    N = B * world
+    inv_scale = 1.0 / N                      # global 1/B: per-rank losses / grads SUM to 1 device
+    d0, labels, idx_local, logits, grads, weights, residuals = make_inputs(torch, dev, B, C, N, rank)
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+
+    def step(i, ws):
+        r = i % ROTATE
+        ops.mstep_fwd_bwd(logits[r], labels, idx_local, weights, residuals, inv_scale=inv_scale,
+                          out=out, grad=grads[r], ws=ws)
+        if world > 1:
+            rdist.exchange_residuals_owned(residuals, rank * B, (rank + 1) * B)
+        ops.estep_deep(residuals, weights, iters=iters, ws=ws)
+
+    def mstep_only(i, ws):
+        r = i % ROTATE
+        ops.mstep_fwd_bwd(logits[r], labels, idx_local, weights, residuals, inv_scale=inv_scale,
+                          out=out, grad=grads[r], ws=ws)
+
+    def estep_only(i, ws):
+        ops.estep_deep(residuals, weights, iters=iters, ws=ws)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- parity gate (rank 0, set 0)
+    parity = {"checked": False}
+    w_before = weights.clone()
+    with torch.cuda.stream(side):
+        ws = ops.Workspace(dev, N, B)
+        torch.cuda.synchronize()
+        step(0, ws)
+        torch.cuda.synchronize()
+        it_gpu = int(iters.item())
+    if rank == 0 and world == 1 and not a.profile_only:
+        from oracle import rlvi_oracle as O        # the checker, never the thing measured
+        res_o = np.zeros(N, np.float32)
+        w_o = w_before.cpu().numpy()
+        ref = O.mstep(d0["logits"], d0["labels"], d0["idx"], w_o, res_o, scale_div=N)
+        it_o = O.update_sample_weights(res_o, w_o)
+        gd = grads[0].cpu().numpy().astype(np.float64) - ref["grad"]
+        wg = weights.cpu().numpy()
+        big = w_o >= 1e-6 * w_o.max()
+        parity = {
+            "checked": True,
+            "loss_rel": abs(float(out[0]) - float(ref["loss"])) / abs(float(ref["loss"])),
+            "grad_rel_fro": float(np.sqrt((gd ** 2).sum()) /
+                                  np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())),
+            "pi_rel_max": float(np.max(np.abs(wg[big] - w_o[big]) / w_o[big])),
+            "estep_iters": [it_gpu, int(it_o)],
+        }
+        parity["ok"] = bool(parity["loss_rel"] <= 1e-5 and parity["grad_rel_fro"] <= 1e-5 and
+                            parity["pi_rel_max"] <= 1e-5 and it_gpu == it_o)
+
+    # ---------------------------------------------------------------- timed regions
+    def timed(fn, K, W, use_graph):
+        """W untimed + exactly K timed invocations on the side stream; returns ms (max over ranks)."""
+        with torch.cuda.stream(side):
+            for i in range(W):
+                fn(i, ws)
+            torch.cuda.synchronize()
+            graph = None
+            if use_graph:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for i in range(K):
+                        fn(W + i, ws)
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sync_all()
+            e0.record(side)
+            if graph is not None:
+                graph.replay()
+            else:
+                for i in range(K):
+                    fn(W + i, ws)
+            e1.record(side)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+        sync_all()
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        return ms
+
+    use_graph = (not a.no_graph) and world == 1     # RCCL calls stay eager
+    K, W = a.steps, a.warmup
+    ms_total = timed(step, K, W, use_graph)
+    ms_step = ms_total / K
+    value = (B * world) / (ms_step * 1e-3)
+
+    result = {
+        "metric": "RLVI samples/sec (fused E+M step)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic logits {B}x{C} per GPU, N={N} samples, "
+                               "M-step (lagged pi) + E-step every step, HBM-cold rotation of "
+                               f"{ROTATE} buffer pairs",
+                   "rows_per_gpu": B, "classes": C, "n_samples": N,
+                   "launch": "hipGraph" if use_graph else "eager"},
+    }
+    if a.profile_only:
+        if rank == 0:
+            print(json.dumps(result))
+        return
+
+    # per-kernel legs (same buffers, same rotation): the HBM-bound M-step kernel and the
+    # latency-bound E-step, each timed alone with HIP events on the launch stream
+    ms_m = timed(mstep_only, K, W, use_graph) / K
+    ms_e = timed(estep_only, K, W, use_graph) / K
+    bytes_per_sample = 2 * C * 4 + 24
+    achieved = B * bytes_per_sample / (ms_m * 1e-3)
+    result["roofline"] = {
+        "bound": "hbm", "kernel": "rlvi::mstep_kernel (+ 1-block finalize)",
+        "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK, "traffic": None,
+        "bytes_per_sample": bytes_per_sample, "us_per_launch": ms_m * 1e3,
+        "step_frac": (B * bytes_per_sample / (ms_step * 1e-3)) / HBM_PEAK,
+    }
+    result["parts"] = {"mstep_us": ms_m * 1e3, "estep_us": ms_e * 1e3,
+                       "estep_iters": it_gpu, "estep_n": N,
+                       "mstep_samples_per_s": B / (ms_m * 1e-3)}
+    result["parity"] = parity
+    st = ws.status()
+    result["device_status"] = st
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import rlvi_oracle as O
+        cores = os.cpu_count() or 1
+        O.set_threads(cores)
+        w_o = w_before.cpu().numpy()
+        res_o = np.zeros(N, np.float32)
+        grad_dummy = None
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            O.mstep(d0["logits"], d0["labels"], d0["idx"], w_o, res_o, scale_div=N)
+            O.update_sample_weights(res_o, w_o)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= a.cpu_seconds or n >= 2000:
+                break
+        result["cpu_baseline"] = {
+            "value": n * B / el, "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"{n} full steps (M-step fwd+bwd + E-step) of the same {B}x{C} workload "
+                      f"in {el:.1f} s, C oracle with OpenMP on {O.num_threads()} threads",
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""Batch sharding of the RLVI hot path over the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference is single-device (no distributed code at all), so the contract is
+"N ranks produce what one device produces on the concatenated batch":
+
+  M-step   rows are independent: every rank streams its own rows with inv_scale = 1/B_global,
+           so the SUM of the per-rank logit gradients / losses equals the single-device result.
+           No data-path collective (the model-gradient all-reduce belongs to DDP).
+  E-step   needs population-wide min / mean / max.  Every rank scatters its rows' NLL into ITS
+           replica of residuals[N]; ONE all-gather makes the replicas identical; then every rank
+           runs the whole fixed point redundantly (bit-identical pi everywhere, zero further
+           collectives).  For N <~ 1e6 that beats 20-40 latency-bound scalar all-reduces
+           (the "epsilon-prior all-reduce" of BASELINE.json, kept as `estep_allreduce_scalars`).
+  threshold / mask: replicated on the identical pi.
+
+Everything here is host logic on top of torch collectives and works on CPU tensors too.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced [start, stop) of n rows for `rank` (first n % world ranks get +1)."""
+    q, r = divmod(int(n), int(world))
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def global_batch(b_local, group=None):
+    """Sum of the per-rank batch sizes (one tiny all-reduce; skip it when shards are equal)."""
+    if not is_dist():
+        return int(b_local)
+    t = torch.tensor([int(b_local)], dtype=torch.int64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, group=group)
+    return int(t.item())
+
+
+def exchange_residuals_owned(residuals, start, stop, group=None):
+    """Every rank owns the contiguous slice [start, stop) of equal length: one
+    all_gather_into_tensor straight into the replicated vector (N = world * (stop-start))."""
+    if not is_dist():
+        return
+    world = dist.get_world_size(group)
+    n = stop - start
+    if residuals.shape[0] != n * world:
+        raise ValueError("owned exchange needs equal contiguous slices covering the vector")
+    dist.all_gather_into_tensor(residuals, residuals[start:stop].clone(), group=group)
+
+
+def exchange_residuals(residuals, idx_local, group=None):
+    """General form (DistributedSampler-style ownership): all-gather (index, value) pairs of the
+    rows this rank visited since the last exchange and scatter them into the local replica.
+    Shards may differ in length (ragged last batch): they are padded to the longest."""
+    if not is_dist():
+        return
+    world = dist.get_world_size(group)
+    dev = residuals.device
+    n_local = torch.tensor([idx_local.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad_idx = torch.zeros(m, dtype=torch.int64, device=dev)
+    pad_val = torch.zeros(m, dtype=residuals.dtype, device=dev)
+    pad_idx[:idx_local.numel()] = idx_local
+    pad_val[:idx_local.numel()] = residuals[idx_local]
+    all_idx = torch.empty(world * m, dtype=torch.int64, device=dev)
+    all_val = torch.empty(world * m, dtype=residuals.dtype, device=dev)
+    dist.all_gather_into_tensor(all_idx, pad_idx, group=group)
+    dist.all_gather_into_tensor(all_val, pad_val, group=group)
+    for r, s in enumerate(sizes):
+        residuals[all_idx[r * m:r * m + s]] = all_val[r * m:r * m + s]
+
+
+def reduce_scalars(t, group=None):
+    """SUM-all-reduce of a small tensor of per-rank partial sums, e.g. {sum pi*l, hits}
+    (once per epoch for logging; the training math never needs it per batch)."""
+    if is_dist():
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def estep_allreduce_scalars(residuals_local, weights_local, n_global, tol=1e-3, maxiter=40,
+                            group=None):
+    """Measured alternative (BASELINE.json's "scalar epsilon-prior all-reduce"): the vectors stay
+    SHARDED by rank; per iteration one packed 2-float SUM all-reduce {sum pi', sum (pi'-pi)^2},
+    plus one MIN before and one MAX after.  Elementwise math is plain torch (this path exists to
+    price the K serial collectives against the single all-gather; it is not the product path).
+    Returns the iteration count."""
+    r, w = residuals_local, weights_local
+    mn = r.min().reshape(1)
+    if is_dist():
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    r.sub_(mn)
+    e = torch.exp(-r)
+    ratio = torch.tensor(0.95 / (1 - 0.95), dtype=r.dtype, device=r.device)
+    it = 0
+    for _ in range(maxiter):
+        new = ratio * e / (1 + ratio * e)
+        s = torch.stack([new.double().sum(), ((new - w).double() ** 2).sum()])
+        if is_dist():
+            dist.all_reduce(s, group=group)
+        w.copy_(new)
+        it += 1
+        err = s[1].sqrt().to(r.dtype)
+        avg = (s[0].to(r.dtype) / n_global)
+        if bool(err < tol):
+            break
+        ratio = avg / (1 - avg)
+    mx = w.max().reshape(1)
+    if is_dist():
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    w.div_(mx)
+    return it

@@ -66,7 +66,7 @@ def workspace(device, n=0, b=0):
 
 
 def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_grad=True,
-                  out=None, grad=None):
+                  out=None, grad=None, ws=None):
     """One mini-batch of the M-step (train_rlvi.py:85-96 without model/optimizer).
 
     Scatters the per-sample NLL into `residuals[idx]`, gathers the lagged pi from
@@ -97,7 +97,7 @@ def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_
         grad = torch.empty((B, C), dtype=logits.dtype, device=logits.device)
     if not want_grad:
         grad = None
-    ws = workspace(logits.device, N, B)
+    ws = ws or workspace(logits.device, N, B)
     fn = L.rlvi_mstep_fwd_bwd_f32 if logits.dtype == torch.float32 else L.rlvi_mstep_fwd_bwd_bf16
     rc = fn(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(idx), _ptr(weights),
             _ptr(residuals), N, B, C, float(inv_scale if inv_scale is not None else 1.0 / B),
@@ -107,7 +107,7 @@ def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_
     return out, grad
 
 
-def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None):
+def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None, ws=None):
     """update_sample_weights (train_rlvi.py:14-38), in place on both vectors."""
     L = _lib.load()
     _require_gpu(residuals, weights)
@@ -117,7 +117,7 @@ def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None)
     if residuals.shape != weights.shape:
         raise ValueError("residuals and weights differ in length")
     N = weights.shape[0]
-    ws = workspace(weights.device, N, 0)
+    ws = ws or workspace(weights.device, N, 0)
     rc = L.rlvi_estep_deep_f32(_ptr(residuals), _ptr(weights), N, float(tol), int(maxiter),
                                _ptr(iters), _ptr(trace), ws.ptr, _stream_ptr())
     _lib.check(rc, "rlvi_estep_deep_f32")
@@ -136,7 +136,7 @@ def fn_threshold(weights, alpha=0.05):
     return thr.reshape(())
 
 
-def threshold_truncate(weights, threshold, alpha=0.05, want_mask=False):
+def threshold_truncate(weights, threshold, alpha=0.05, want_mask=False, ws=None):
     """train_rlvi.py:102-103: threshold = max(threshold, criterion); weights[weights<thr] = 0.
 
     Returns (threshold 0-dim tensor, mask bool tensor or None, kept int64 0-dim tensor)."""
@@ -148,14 +148,15 @@ def threshold_truncate(weights, threshold, alpha=0.05, want_mask=False):
     thr = torch.as_tensor(threshold, dtype=torch.float32, device=weights.device).reshape(1).clone()
     mask = torch.empty(N, dtype=torch.uint8, device=weights.device) if want_mask else None
     kept = torch.zeros(1, dtype=torch.int64, device=weights.device)
-    ws = workspace(weights.device, N, 0)
+    ws = ws or workspace(weights.device, N, 0)
     _lib.check(L.rlvi_threshold_truncate_f32(_ptr(weights), N, float(alpha), _ptr(thr), _ptr(mask),
                                              _ptr(kept), ws.ptr, _stream_ptr()),
                "rlvi_threshold_truncate_f32")
     return thr.reshape(()), (mask.bool() if want_mask else None), kept.reshape(())
 
 
-def fused_em(logits, labels, pi, tol=1e-3, maxiter=40, inv_scale=None, want_grad=True):
+def fused_em(logits, labels, pi, tol=1e-3, maxiter=40, inv_scale=None, want_grad=True, ws=None,
+             out=None, grad=None, rows=None, iters=None):
     """In-batch E+M (online order): NLL -> E-step on this batch -> weighted loss + grad.
 
     `pi` [B] fp32 is read (first error only) and overwritten with the new posteriors.
@@ -168,11 +169,17 @@ def fused_em(logits, labels, pi, tol=1e-3, maxiter=40, inv_scale=None, want_grad
         logits = logits.contiguous()
     labels = labels.to(torch.int64).contiguous()
     B, C = logits.shape
-    out = torch.empty(4, dtype=torch.float32, device=logits.device)
-    grad = torch.empty((B, C), dtype=torch.float32, device=logits.device) if want_grad else None
-    rows = torch.empty(B, dtype=torch.float32, device=logits.device)
-    iters = torch.zeros(1, dtype=torch.int32, device=logits.device)
-    ws = workspace(logits.device, B, B)
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    if want_grad and grad is None:
+        grad = torch.empty((B, C), dtype=torch.float32, device=logits.device)
+    if not want_grad:
+        grad = None
+    if rows is None:
+        rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if iters is None:
+        iters = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    ws = ws or workspace(logits.device, B, B)
     rc = L.rlvi_fused_em_f32(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(rows), _ptr(pi),
                              B, C, float(inv_scale if inv_scale is not None else 1.0 / B),
                              float(tol), int(maxiter), _ptr(grad),
