@@ -49,8 +49,9 @@ void rlvi_oracle_set_threads(int n) {
  *   deep-learning/methods/train_rlvi.py:89  F.cross_entropy(reduction='none')
  *   deep-learning/utils.py:65-79            accuracy(): softmax -> topk -> eq
  * log-softmax is evaluated the way torch does it: (z - max) - log(sum exp).
- * Top-1 hit: label == argmax (first maximal index on ties; the reference's
- * topk tie order is unspecified, so ties are "parity unpinned").
+ * Top-1 hit: the label's logit attains the row maximum.  When several columns tie
+ * for the maximum the reference's topk picks one of them in an unspecified order,
+ * so tied rows are "parity unpinned" (tests allow exactly those rows).
  * ------------------------------------------------------------------------- */
 static inline void row_stats_f32(const float *z, int64_t C, float *m_out,
                                  float *logs_out, int64_t *amax_out) {
@@ -76,7 +77,7 @@ void rlvi_oracle_nll_rows_f32(const float *logits, int64_t ld,
         row_stats_f32(z, C, &m, &logs, &am);
         const int64_t y = labels[i];
         loss[i] = -((z[y] - m) - logs);
-        if (hit) hit[i] = (am == y);
+        if (hit) hit[i] = (z[y] == m);
     }
 }
 
@@ -116,7 +117,7 @@ int rlvi_oracle_mstep_f32(const float *logits, int64_t ld,
         const float pi = weights[idx[i]];      /* :92  gather (lagged pi) */
         lrow[i] = li;
         acc += (double)(li * pi);              /* :93 */
-        hits += (am == y);
+        hits += (z[y] == m);
         if (grad) {
             const float g = pi * invB;
             float *gr = grad + i * ldg;

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librlvi_gfx950.so")
+# RLVI_LIB_PATH: load a differently-built copy of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RLVI_LIB_PATH") or os.path.join(HERE, "librlvi_gfx950.so")
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

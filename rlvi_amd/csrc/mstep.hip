@@ -11,12 +11,29 @@
 // holding K vectors of V elements (16 B per lane per load when the row pitch allows), so a wave
 // works on 64/G rows at once and a row is read exactly once and written exactly once.  Row
 // reductions (max, sum-exp, arg-max) are butterfly shuffles inside the lane group.
+#include <stdlib.h>
+
 #include "rlvi_common.h"
 
 namespace rlvi {
 
+#ifndef RLVI_MSTEP_NT
+#define RLVI_MSTEP_NT 0   // bit 0: nontemporal row loads, bit 1: nontemporal gradient stores
+#endif
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
+typedef unsigned int vu2 __attribute__((ext_vector_type(2)));
+
 template <typename T, int V>
 struct VecIO;
+
+// default streaming forms = the plain forms (specialisations below override where it pays)
+template <typename T, int V, class Self>
+struct VecIOBase {
+    static __device__ __forceinline__ void load_stream(const T *p, float (&v)[V]) { Self::load(p, v); }
+    static __device__ __forceinline__ void store_stream(T *p, const float (&v)[V]) { Self::store(p, v); }
+};
 
 template <>
 struct VecIO<float, 4> {
@@ -27,9 +44,26 @@ struct VecIO<float, 4> {
     static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    // streaming forms: read-once / write-once data bypasses cache retention (`nt`)
+    static __device__ __forceinline__ void load_stream(const float *p, float (&v)[4]) {
+#if RLVI_MSTEP_NT & 1
+        const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+#else
+        load(p, v);
+#endif
+    }
+    static __device__ __forceinline__ void store_stream(float *p, const float (&v)[4]) {
+#if RLVI_MSTEP_NT & 2
+        const vf4 t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<vf4 *>(p));
+#else
+        store(p, v);
+#endif
+    }
 };
 template <>
-struct VecIO<float, 2> {
+struct VecIO<float, 2> : VecIOBase<float, 2, VecIO<float, 2>> {
     static __device__ __forceinline__ void load(const float *p, float (&v)[2]) {
         const float2 t = *reinterpret_cast<const float2 *>(p);
         v[0] = t.x; v[1] = t.y;
@@ -39,12 +73,12 @@ struct VecIO<float, 2> {
     }
 };
 template <>
-struct VecIO<float, 1> {
+struct VecIO<float, 1> : VecIOBase<float, 1, VecIO<float, 1>> {
     static __device__ __forceinline__ void load(const float *p, float (&v)[1]) { v[0] = *p; }
     static __device__ __forceinline__ void store(float *p, const float (&v)[1]) { *p = v[0]; }
 };
 template <>
-struct VecIO<uint16_t, 8> {
+struct VecIO<uint16_t, 8> : VecIOBase<uint16_t, 8, VecIO<uint16_t, 8>> {
     static __device__ __forceinline__ void load(const uint16_t *p, float (&v)[8]) {
         const uint4 t = *reinterpret_cast<const uint4 *>(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
@@ -63,7 +97,7 @@ struct VecIO<uint16_t, 8> {
     }
 };
 template <>
-struct VecIO<uint16_t, 4> {
+struct VecIO<uint16_t, 4> : VecIOBase<uint16_t, 4, VecIO<uint16_t, 4>> {
     static __device__ __forceinline__ void load(const uint16_t *p, float (&v)[4]) {
         const uint2 t = *reinterpret_cast<const uint2 *>(p);
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
@@ -77,7 +111,7 @@ struct VecIO<uint16_t, 4> {
     }
 };
 template <>
-struct VecIO<uint16_t, 2> {
+struct VecIO<uint16_t, 2> : VecIOBase<uint16_t, 2, VecIO<uint16_t, 2>> {
     static __device__ __forceinline__ void load(const uint16_t *p, float (&v)[2]) {
         const uint32_t t = *reinterpret_cast<const uint32_t *>(p);
         v[0] = __uint_as_float(t << 16); v[1] = __uint_as_float(t & 0xFFFF0000u);
@@ -88,7 +122,7 @@ struct VecIO<uint16_t, 2> {
     }
 };
 template <>
-struct VecIO<uint16_t, 1> {
+struct VecIO<uint16_t, 1> : VecIOBase<uint16_t, 1, VecIO<uint16_t, 1>> {
     static __device__ __forceinline__ void load(const uint16_t *p, float (&v)[1]) {
         v[0] = bf16_to_f32(*p);
     }
@@ -100,11 +134,28 @@ struct VecIO<uint16_t, 1> {
 constexpr int MSTEP_THREADS = 256;
 constexpr int MSTEP_WAVES = MSTEP_THREADS / WAVE;
 
-template <typename T, int V, int G, int K>
+// exp(d) for d = z - max <= 0: one multiply by log2(e) and v_exp_f32.  d is an exact-to-1-ulp
+// fp32 difference, so the argument error is |d|*log2(e)*2^-24: below 1e-7 relative for every
+// term that is not already negligible against sum >= 1 (set RLVI_MSTEP_FAST_EXP=0 for ocml expf).
+#ifndef RLVI_MSTEP_FAST_EXP
+#define RLVI_MSTEP_FAST_EXP 1
+#endif
+__device__ __forceinline__ float mexp(float x) {
+#if RLVI_MSTEP_FAST_EXP
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#else
+    return expf(x);
+#endif
+}
+
+// A row is owned by G consecutive lanes; lane g holds the vectors k*G+g, k < kact <= KMAX, so one
+// load instruction reads G*V contiguous elements of each of the wave's 64/G rows and a lane
+// amortises the (short) lane-group reductions over up to KMAX*V elements.
+template <typename T, int V, int G, int KMAX>
 __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
     const T *__restrict__ logits, int64_t ld, const int64_t *__restrict__ labels,
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
-    float *__restrict__ residuals, int64_t N, int64_t B, int C, float inv_scale,
+    float *__restrict__ residuals, int64_t N, int64_t B, int C, int kact, float inv_scale,
     T *__restrict__ grad, int64_t ldg, double *__restrict__ part, int32_t *__restrict__ status) {
     constexpr int R = WAVE / G;  // rows per wave
     const int lane = threadIdx.x & (WAVE - 1);
@@ -124,52 +175,61 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
         const int64_t rr = valid ? row : B - 1;   // padding rows recompute the last row, store nothing
         const T *zrow = logits + rr * ld;
 
-        float v[K][V];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int col = (k * G + g) * V;
-            if (col < C) {
-                VecIO<T, V>::load(zrow + col, v[k]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < V; ++j) v[k][j] = NEG_INF;
-            }
-        }
+        // Issue order matters: the small label / index reads go FIRST so that they return ahead
+        // of the row data (loads of a wave return in order) and the dependent pi gather and
+        // label-logit read are already queued while the row vectors are still in flight --
+        // otherwise they cost a second full memory round trip behind everybody's row data.
         int64_t y64 = labels[rr];
-        int64_t ix = idx != nullptr ? idx[rr] : rr;   // idx == NULL: identity (in-batch E+M)
+        int64_t ix = (idx != nullptr ? idx : labels)[rr];   // unconditional load, selected below
+
+        // branch-free row loads: a lane's unused vector slots re-read its first vector (always in
+        // range, same cache line) and are masked to -inf afterwards, so the compiler can count
+        // the outstanding loads instead of draining them at a branch
+        float v[KMAX][V];
+        bool live[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int col = (k * G + g) * V;
+            live[k] = k < kact && col < C;
+            VecIO<T, V>::load_stream(zrow + (live[k] ? col : g * V), v[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ix = idx != nullptr ? ix : rr;                // idx == NULL: identity (in-batch E+M)
         bool row_ok = valid;
         if (y64 < 0 || y64 >= C) { y64 = 0; bad = bad || valid; row_ok = false; }
         if (ix < 0 || ix >= N) { ix = 0; bad = bad || valid; row_ok = false; }
         const int y = (int)y64;
         const float pi = weights[ix];
+        // the label logit again (one 4-byte read of a line this wave has just requested)
+        float zy;
+        {
+            float t[1];
+            VecIO<T, 1>::load(zrow + y, t);
+            zy = t[0];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the two dependent reads queued behind the row data
 
         float m = NEG_INF;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int k = 0; k < KMAX; ++k)
 #pragma unroll
-            for (int j = 0; j < V; ++j) m = fmaxf(m, v[k][j]);
+            for (int j = 0; j < V; ++j) {
+                v[k][j] = live[k] ? v[k][j] : NEG_INF;
+                m = fmaxf(m, v[k][j]);
+            }
         m = group_max<G>(m);
 
         float s = 0.0f;
-        int first = 0x7FFFFFFF;
-        float cand = 0.0f;
-        const int yv = y / V, jy = y - yv * V;
-        const int ky = yv / G, gy = yv & (G - 1);
 #pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
+        for (int k = 0; k < KMAX; ++k) {
 #pragma unroll
-            for (int j = V - 1; j >= 0; --j) {
-                const float z = v[k][j];
-                if (z == m) first = (k * G + g) * V + j;   // descending scan keeps the lowest column
-                if (k == ky && j == jy) cand = z;
-                const float e = expf(z - m);
+            for (int j = 0; j < V; ++j) {
+                const float e = mexp(v[k][j] - m);
                 v[k][j] = e;
                 s += e;
             }
         }
         s = group_sum<G>(s);
-        const int amax = group_min_i<G>(first);
-        const float zy = __shfl(cand, sub * G + gy, WAVE);
         const float logs = logf(s);
         const float li = logs - (zy - m);   // == -((z_y - max) - log(sum exp)), as torch evaluates it
 
@@ -178,9 +238,9 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
             const float inv_s = gs / s;
             T *grow = grad + rr * ldg;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+            for (int k = 0; k < KMAX; ++k) {
                 const int col = (k * G + g) * V;
-                if (col < C) {
+                if (live[k]) {
                     float o[V];
 #pragma unroll
                     for (int j = 0; j < V; ++j) {
@@ -188,18 +248,221 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
                         if (col + j == y) p -= gs;
                         o[j] = p;
                     }
-                    VecIO<T, V>::store(grow + col, o);
+                    VecIO<T, V>::store_stream(grow + col, o);
                 }
             }
         }
         if (g == 0 && row_ok) {
             if (residuals != nullptr) residuals[ix] = li;
             acc += li * pi;
-            hits += (amax == y) ? 1.0f : 0.0f;
+            hits += (zy == m) ? 1.0f : 0.0f;   // top-1: the label attains the row maximum
         }
     }
 
     // block partials -> workspace (fixed order: deterministic)
+    double a = wave_sum((double)acc);
+    double h = wave_sum((double)hits);
+    __shared__ double sh[2 * MSTEP_WAVES];
+    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = h; }
+    if (bad) atomicOr(status, RLVI_ST_RANGE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, th = 0.0;
+#pragma unroll
+        for (int w = 0; w < MSTEP_WAVES; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
+        part[2 * blockIdx.x] = ta;
+        part[2 * blockIdx.x + 1] = th;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Tile form (dense rows, ld == C): the workgroup streams a tile of TR = 256/G rows through LDS.
+//   A  flat, fully coalesced 16-B/lane nontemporal loads of the tile (whole 128-B lines per
+//      wave instruction whatever C is) -> LDS; one thread per row fetches label, index, pi
+//   B  rows are processed out of LDS by G-lane groups exactly as in the register form; the
+//      gradient is written back into the tile in place
+//   C  flat nontemporal 16-B/lane stores of the tile to grad
+// Fragment-shaped global accesses (64/G row segments per instruction) keep the texture
+// addresser 2x busier for the same traffic and forbid `nt` (every line is touched by two
+// instructions); the flat form is what the copy ceiling is measured with.
+// ---------------------------------------------------------------------------------------
+template <typename T, int V, int G, int KMAX>
+__global__ __launch_bounds__(MSTEP_THREADS) void mstep_tile_kernel(
+    const T *__restrict__ logits, const int64_t *__restrict__ labels,
+    const int64_t *__restrict__ idx, const float *__restrict__ weights,
+    float *__restrict__ residuals, int64_t N, int64_t B, int C, int kact, float inv_scale,
+    T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status) {
+    constexpr int TR = MSTEP_THREADS / G;          // rows per tile
+    constexpr int R = WAVE / G;                    // rows per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t tile_bytes = (size_t)TR * C * sizeof(T);       // multiple of 16 (host-checked)
+    T *tile = reinterpret_cast<T *>(smem);
+    int64_t *s_ix = reinterpret_cast<int64_t *>(smem + tile_bytes);
+    float *s_pi = reinterpret_cast<float *>(s_ix + TR);
+    int *s_y = reinterpret_cast<int *>(s_pi + TR);
+    T *pad = reinterpret_cast<T *>(s_y + TR);                   // 16 bytes of -inf
+    vu4 *tile16 = reinterpret_cast<vu4 *>(smem);
+    if (threadIdx.x < 16 / sizeof(T)) {
+        float ninf[1] = {-__builtin_inff()};
+        VecIO<T, 1>::store(pad + threadIdx.x, ninf);
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = tid / WAVE;
+    const int g = lane & (G - 1);
+    const int sub = lane / G;
+    const float NEG_INF = -__builtin_inff();
+    const int nchunk = (int)(tile_bytes / 16);
+    const int64_t ntiles = (B + TR - 1) / TR;
+
+    float acc = 0.0f, hits = 0.0f;
+    bool bad = false;
+
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t row_base = t * TR;
+        const int rows_here = (int)((B - row_base) < TR ? (B - row_base) : TR);
+        const T *gsrc = logits + row_base * C;
+        // ---- A: per-row scalars first (they return ahead of the tile data), then the tile
+        const int64_t myrow = row_base + (tid < rows_here ? tid : rows_here - 1);
+        int64_t y64 = labels[myrow];
+        int64_t ix = (idx != nullptr ? idx : labels)[myrow];
+        if (rows_here == TR) {
+            vu4 stage[KMAX];
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) {
+                int i = c * MSTEP_THREADS + tid;
+                i = i < nchunk ? i : nchunk - 1;             // branch-free: tail lanes re-read
+                stage[c] = __builtin_nontemporal_load(reinterpret_cast<const vu4 *>(gsrc) + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ix = idx != nullptr ? ix : myrow;
+            bool okrow = true;
+            if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
+            if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
+            const float pi = weights[ix];
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid < TR) {
+                s_ix[tid] = ix;
+                s_pi[tid] = pi;
+                s_y[tid] = okrow ? (int)y64 : -1;
+                bad = bad || !okrow;
+            }
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) {
+                const int i = c * MSTEP_THREADS + tid;
+                if (i < nchunk) tile16[i] = stage[c];
+            }
+        } else {
+            // ragged last tile: element-granular copy (never reads past the tensor)
+            ix = idx != nullptr ? ix : myrow;
+            bool okrow = true;
+            if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
+            if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
+            const float pi = weights[ix];
+            if (tid < rows_here) {
+                s_ix[tid] = ix;
+                s_pi[tid] = pi;
+                s_y[tid] = okrow ? (int)y64 : -1;
+                bad = bad || !okrow;
+            }
+#pragma unroll 1
+            for (int e = tid; e < rows_here * C; e += MSTEP_THREADS) tile[e] = gsrc[e];
+        }
+        __syncthreads();
+
+        // ---- B: one lane group per row, out of LDS
+        {
+            const int r_raw = wave * R + sub;
+            const bool valid = r_raw < rows_here;
+            const int r = valid ? r_raw : rows_here - 1;
+            T *zrow = tile + (size_t)r * C;
+            const int ys = s_y[r];
+            const bool row_ok = valid && ys >= 0;
+            const int y = ys >= 0 ? ys : 0;
+            const float pi = s_pi[r];
+            float zy;
+            {
+                float tt[1];
+                VecIO<T, 1>::load(zrow + y, tt);
+                zy = tt[0];
+            }
+            // unused vector slots of a lane read a 16-byte pad of -inf: no per-element masking
+            float v[KMAX][V];
+            bool live[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int col = (k * G + g) * V;
+                live[k] = k < kact && col < C;
+                VecIO<T, V>::load(live[k] ? zrow + col : pad, v[k]);
+            }
+            float m = NEG_INF;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int j = 0; j < V; ++j) m = fmaxf(m, v[k][j]);
+            m = group_max<G>(m);
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float e = mexp(v[k][j] - m);
+                    v[k][j] = e;
+                    s += e;
+                }
+            s = group_sum<G>(s);
+            const float logs = logf(s);
+            const float li = logs - (zy - m);
+            if (grad != nullptr) {
+                const float gs = pi * inv_scale;
+                const float inv_s = gs / s;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int col = (k * G + g) * V;
+                    if (live[k] && valid) {
+                        float o[V];
+#pragma unroll
+                        for (int j = 0; j < V; ++j) {
+                            o[j] = v[k][j] * inv_s;
+                            if (sizeof(T) != 4 && col + j == y) o[j] -= gs;
+                        }
+                        VecIO<T, V>::store(zrow + col, o);     // in place, same lane that read it
+                    }
+                }
+                if (sizeof(T) == 4 && g == 0 && valid) {
+                    // -onehot term: one read-modify-write of the label entry, ordered behind
+                    // this wave's vector stores (LDS operations of a wave complete in order)
+                    float *zf = reinterpret_cast<float *>(zrow);
+                    zf[y] = zf[y] - gs;
+                }
+            }
+            if (g == 0 && row_ok) {
+                if (residuals != nullptr) residuals[s_ix[r]] = li;
+                acc += li * pi;
+                hits += (zy == m) ? 1.0f : 0.0f;
+            }
+        }
+
+        // ---- C: flat store of the gradient tile
+        if (grad != nullptr) {
+            __syncthreads();
+            T *gdst = grad + row_base * C;
+            if (rows_here == TR) {
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    const int i = c * MSTEP_THREADS + tid;
+                    if (i < nchunk)
+                        __builtin_nontemporal_store(tile16[i], reinterpret_cast<vu4 *>(gdst) + i);
+                }
+            } else {
+#pragma unroll 1
+                for (int e = tid; e < rows_here * C; e += MSTEP_THREADS) gdst[e] = tile[e];
+            }
+        }
+        __syncthreads();      // the tile is rewritten by the next iteration
+    }
+
     double a = wave_sum((double)acc);
     double h = wave_sum((double)hits);
     __shared__ double sh[2 * MSTEP_WAVES];
@@ -238,22 +501,46 @@ __global__ __launch_bounds__(256) void mstep_finalize_kernel(const double *__res
     }
 }
 
-template <typename T, int V, int G, int K>
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <typename T, int V, int G, int KMAX>
 static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, const int64_t *idx,
                         const float *weights, float *residuals, int64_t N, int64_t B, int C,
-                        float inv_scale, T *grad, int64_t ldg, float *out, void *ws,
+                        int kact, float inv_scale, T *grad, int64_t ldg, float *out, void *ws,
                         hipStream_t st) {
     constexpr int R = WAVE / G;
-    const int64_t rows_per_block = (int64_t)MSTEP_WAVES * R;
-    int64_t nb = (B + rows_per_block - 1) / rows_per_block;
-    if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
-    if (nb < 1) nb = 1;
+    constexpr int TR = MSTEP_THREADS / G;
+    static const int max_blocks = env_int("RLVI_MSTEP_BLOCKS", MSTEP_MAX_BLOCKS);
+    static const int use_tile = env_int("RLVI_MSTEP_TILE", 1);
     char *base = static_cast<char *>(ws);
     double *part = reinterpret_cast<double *>(base + WS_PART_OFF);
     int32_t *status = reinterpret_cast<int32_t *>(base);
-    hipLaunchKernelGGL((mstep_kernel<T, V, G, K>), dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st,
-                       logits, ld, labels, idx, weights, residuals, N, B, C, inv_scale, grad, ldg,
-                       part, status);
+    const size_t tile_bytes = (size_t)TR * C * sizeof(T);
+    const bool dense = ld == C && (grad == nullptr || ldg == C) && tile_bytes % 16 == 0 &&
+                       ((uintptr_t)logits % 16) == 0 && ((uintptr_t)grad % 16) == 0 &&
+                       (tile_bytes + 15) / 16 <= (size_t)KMAX * MSTEP_THREADS;
+    int64_t nb;
+    if (dense && use_tile) {
+        nb = (B + TR - 1) / TR;
+        if (nb > max_blocks) nb = max_blocks;
+        if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
+        const size_t lds = tile_bytes + (size_t)TR * 16 + 16;
+        hipLaunchKernelGGL((mstep_tile_kernel<T, V, G, KMAX>), dim3((unsigned)nb),
+                           dim3(MSTEP_THREADS), lds, st, logits, labels, idx, weights, residuals,
+                           N, B, C, kact, inv_scale, grad, part, status);
+    } else {
+        const int64_t rows_per_block = (int64_t)MSTEP_WAVES * R;
+        nb = (B + rows_per_block - 1) / rows_per_block;
+        if (nb > max_blocks) nb = max_blocks;
+        if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL((mstep_kernel<T, V, G, KMAX>), dim3((unsigned)nb), dim3(MSTEP_THREADS),
+                           0, st, logits, ld, labels, idx, weights, residuals, N, B, C, kact,
+                           inv_scale, grad, ldg, part, status);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, inv_scale,
@@ -262,29 +549,39 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
     return (int)e;
 }
 
-// Picks (V, G, K): V from the alignment of base pointers / pitches / C, then the smallest lane
-// group that covers ceil(C/V) vectors with at most 8 vectors per lane.
+// Picks the lane group: the smallest G whose lanes need at most 8 vectors each (so the short
+// DPP reductions are amortised over up to 8*V elements per lane); rows of <= 8 vectors are
+// handled by a single lane.
 template <typename T, int V>
 static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const int64_t *idx,
                        const float *weights, float *residuals, int64_t N, int64_t B, int C,
                        float inv_scale, T *grad, int64_t ldg, float *out, void *ws,
                        hipStream_t st) {
     const int nv = (C + V - 1) / V;
+    static const int force_g = env_int("RLVI_MSTEP_G", 0);
 #define RLVI_CASE(G_, K_)                                                                        \
     return launch_mstep<T, V, G_, K_>(logits, ld, labels, idx, weights, residuals, N, B, C,      \
-                                      inv_scale, grad, ldg, out, ws, st)
-    if (nv <= 1) RLVI_CASE(1, 1);
-    if (nv <= 2) RLVI_CASE(2, 1);
-    if (nv <= 4) RLVI_CASE(4, 1);
-    if (nv <= 8) RLVI_CASE(8, 1);
-    if (nv <= 16) RLVI_CASE(16, 1);
-    if (nv <= 32) RLVI_CASE(32, 1);
-    if (nv <= 64) RLVI_CASE(64, 1);
-    if (nv <= 128) RLVI_CASE(64, 2);
-    if (nv <= 256) RLVI_CASE(64, 4);
-    if (nv <= 512) RLVI_CASE(64, 8);
+                                      (nv + G_ - 1) / G_, inv_scale, grad, ldg, out, ws, st)
+    int gsel = 64;
+    for (int gg = 1; gg <= 64; gg <<= 1)
+        if ((nv + gg - 1) / gg <= 8) { gsel = gg; break; }
+    if (force_g && (nv + force_g - 1) / force_g <= 8) gsel = force_g;
+    const int k = (nv + gsel - 1) / gsel;
+    if (k > 8) return RLVI_E_LIMIT;
+    switch (gsel) {
+        case 1:
+            if (k <= 1) RLVI_CASE(1, 1);
+            if (k <= 2) RLVI_CASE(1, 2);
+            if (k <= 4) RLVI_CASE(1, 4);
+            RLVI_CASE(1, 8);
+        case 2: if (k <= 4) RLVI_CASE(2, 4); RLVI_CASE(2, 8);
+        case 4: if (k <= 4) RLVI_CASE(4, 4); RLVI_CASE(4, 8);
+        case 8: if (k <= 4) RLVI_CASE(8, 4); RLVI_CASE(8, 8);
+        case 16: if (k <= 4) RLVI_CASE(16, 4); RLVI_CASE(16, 8);
+        case 32: if (k <= 4) RLVI_CASE(32, 4); RLVI_CASE(32, 8);
+        default: if (k <= 4) RLVI_CASE(64, 4); RLVI_CASE(64, 8);
+    }
 #undef RLVI_CASE
-    return RLVI_E_LIMIT;
 }
 
 template <typename T>

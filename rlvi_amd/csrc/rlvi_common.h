@@ -40,56 +40,99 @@ __host__ __device__ inline size_t ws_bytes_for(int64_t max_n, int64_t max_b) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Wave (64-lane) butterfly reductions.  a+b is commutative in IEEE arithmetic, so after
-// the butterfly every lane holds bit-identical totals, in a fixed association order.
+// Cross-lane all-reduce steps without LDS traffic (gfx950):
+//   xor 1, 2   DPP quad_perm            xor 4   DPP row_half_mirror (lanes of a quad already agree)
+//   xor 8      DPP row_mirror           xor 16  v_permlane16_swap   xor 32  v_permlane32_swap
+// Every step pairs two lane sets that already hold identical values, so for a commutative op the
+// result is the butterfly all-reduce: all lanes end with bit-identical totals, fixed order.
 // ---------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
-template <typename T>
-__device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        T u = __shfl_xor(v, o, WAVE);
-        v = u > v ? u : v;
-    }
-    return v;
+template <int CTRL>
+__device__ __forceinline__ float dpp_x(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ int dpp_x(int v) { return dpp_i<CTRL>(v); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_x(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>((int)(unsigned)(b & 0xFFFFFFFFll));
+    const int hi = dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-template <typename T>
-__device__ __forceinline__ T wave_min(T v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        T u = __shfl_xor(v, o, WAVE);
-        v = u < v ? u : v;
-    }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_x(unsigned long long v) {
+    const int lo = dpp_i<CTRL>((int)(unsigned)(v & 0xFFFFFFFFull));
+    const int hi = dpp_i<CTRL>((int)(v >> 32));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// {a, b}: a = lanes' own-or-partner value arranged so that op(a, b) is the xor-16 / xor-32 step
+template <int W>
+__device__ __forceinline__ void swap_pair(int v, int &a, int &b) {
+    if (W == 16) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); a = r[0]; b = r[1]; }
+    else { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); a = r[0]; b = r[1]; }
+}
+template <int W, class Op>
+__device__ __forceinline__ float swap_step(float v, Op op) {
+    int a, b;
+    swap_pair<W>(__float_as_int(v), a, b);
+    return op(__int_as_float(a), __int_as_float(b));
+}
+template <int W, class Op>
+__device__ __forceinline__ int swap_step(int v, Op op) {
+    int a, b;
+    swap_pair<W>(v, a, b);
+    return op(a, b);
+}
+template <int W, class Op>
+__device__ __forceinline__ double swap_step(double v, Op op) {
+    const long long bits = __double_as_longlong(v);
+    int alo, blo, ahi, bhi;
+    swap_pair<W>((int)(unsigned)(bits & 0xFFFFFFFFll), alo, blo);
+    swap_pair<W>((int)(bits >> 32), ahi, bhi);
+    return op(__longlong_as_double(((long long)ahi << 32) | (unsigned)alo),
+              __longlong_as_double(((long long)bhi << 32) | (unsigned)blo));
+}
+template <int W, class Op>
+__device__ __forceinline__ unsigned long long swap_step(unsigned long long v, Op op) {
+    int alo, blo, ahi, bhi;
+    swap_pair<W>((int)(unsigned)(v & 0xFFFFFFFFull), alo, blo);
+    swap_pair<W>((int)(v >> 32), ahi, bhi);
+    return op(((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo,
+              ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo);
+}
+
+// All-reduce inside groups of G consecutive lanes (G a power of two, 1..64).
+template <int G, typename T, class Op>
+__device__ __forceinline__ T group_allreduce(T v, Op op) {
+    if (G >= 2) v = op(v, dpp_x<0xB1>(v));     // quad_perm [1,0,3,2]
+    if (G >= 4) v = op(v, dpp_x<0x4E>(v));     // quad_perm [2,3,0,1]
+    if (G >= 8) v = op(v, dpp_x<0x141>(v));    // row_half_mirror
+    if (G >= 16) v = op(v, dpp_x<0x140>(v));   // row_mirror
+    if (G >= 32) v = swap_step<16>(v, op);
+    if (G >= 64) v = swap_step<32>(v, op);
     return v;
 }
 
-// Reductions inside a lane group of G consecutive lanes (G a power of two <= 64).
+struct FAdd { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct FMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; } };
+struct FMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; } };
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) { return group_allreduce<WAVE>(v, FAdd()); }
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) { return group_allreduce<WAVE>(v, FMax()); }
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) { return group_allreduce<WAVE>(v, FMin()); }
+
 template <int G>
-__device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
+__device__ __forceinline__ float group_max(float v) { return group_allreduce<G>(v, FMax()); }
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_allreduce<G>(v, FAdd()); }
 template <int G>
-__device__ __forceinline__ int group_min_i(int v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) {
-        int u = __shfl_xor(v, o, WAVE);
-        v = u < v ? u : v;
-    }
-    return v;
-}
+__device__ __forceinline__ int group_min_i(int v) { return group_allreduce<G>(v, FMin()); }
 
 // Order-preserving key of an fp32 value (ascending value <=> ascending unsigned key).
 __device__ __forceinline__ uint32_t f32_key(float f) {

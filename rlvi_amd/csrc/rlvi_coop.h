@@ -39,10 +39,12 @@ struct OpMax {
 };
 
 template <class Op>
+struct OpFn {
+    __device__ __forceinline__ double operator()(double a, double b) const { return Op::apply(a, b); }
+};
+template <class Op>
 __device__ __forceinline__ double wave_reduce(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = Op::apply(v, __shfl_xor(v, o, WAVE));
-    return v;
+    return group_allreduce<WAVE>(v, OpFn<Op>());
 }
 
 constexpr unsigned long long SPIN_BOUND_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Times single legs of the hot path (HIP events, hipGraph of K launches, rotating buffers).
+Used for kernel tuning sweeps:  RLVI_MSTEP_U=2 python tools/time_parts.py --what mstep"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from rlvi_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--what", default="mstep", choices=["mstep", "estep", "thr", "fused", "mstep_fwd"])
+ap.add_argument("--rows", type=int, default=65536)
+ap.add_argument("--classes", type=int, default=100)
+ap.add_argument("--n", type=int, default=0, help="E-step / threshold vector length (default rows)")
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--dtype", default="f32")
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+B, C = a.rows, a.classes
+N = a.n or B
+d0, labels, idx, logits, grads, weights, residuals = bench.make_inputs(torch, dev, B, C, B, 0)
+if a.dtype == "bf16":
+    logits = [z.to(torch.bfloat16) for z in logits]
+    grads = [g.to(torch.bfloat16) for g in grads]
+if N != B:
+    from rlvi_amd import synth
+    residuals_n = torch.from_numpy(synth.residual_vector("bimodal", N, 1)).to(dev)
+    weights_n = torch.ones(N, device=dev)
+out = torch.empty(4, device=dev)
+iters = torch.zeros(1, dtype=torch.int32, device=dev)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    ws = ops.Workspace(dev, max(N, B), B)
+    if N == B:
+        ops.mstep_fwd_bwd(logits[0], labels, idx, weights, residuals, out=out, grad=grads[0], ws=ws)
+        res_src = residuals.clone()
+    else:
+        res_src = residuals_n.clone()
+        residuals, weights = residuals_n, weights_n
+    pi = torch.ones(B, device=dev)
+    rows = torch.empty(B, device=dev)
+    thr = torch.zeros(1, device=dev)
+
+    def leg(i):
+        r = i % bench.ROTATE
+        if a.what == "mstep":
+            ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, out=out, grad=grads[r], ws=ws)
+        elif a.what == "mstep_fwd":
+            ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, out=out, want_grad=False, ws=ws)
+        elif a.what == "estep":
+            residuals.copy_(res_src)
+            ops.estep_deep(residuals, weights, iters=iters, ws=ws)
+        elif a.what == "thr":
+            ops.threshold_truncate(weights, 0.0, ws=ws)
+        elif a.what == "fused":
+            ops.fused_em(logits[r], labels, pi, ws=ws, out=out, grad=grads[r], rows=rows, iters=iters)
+    for i in range(12):
+        leg(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for i in range(a.steps):
+            leg(i)
+    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        g.replay()
+        e1.record(side)
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / a.steps * 1e3)
+    extra = ""
+    if a.what in ("mstep", "mstep_fwd"):
+        s = 2 if a.dtype == "bf16" else 4
+        byt = B * ((2 if a.what == "mstep" else 1) * C * s + 24)
+        extra = f" {byt / best / 1e3:8.1f} GB/s  frac {byt / best / 1e3 / 8000:.3f}"
+    if a.what in ("estep", "fused"):
+        extra = f" iters {int(iters)}"
+    print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
