@@ -64,7 +64,13 @@ int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream);
  *   grad_logits [B, C] (ldg) or NULL for forward only: inv_scale*pi_i*(softmax - onehot)
  *   out         [4] fp32 device: { sum_i pi_i*l_i * inv_scale, 100*hits/B, sum_i pi_i*l_i, hits }
  * bf16 variant: logits / grad_logits are bfloat16, arithmetic is fp32 on the widened values.
- * ------------------------------------------------------------------------------------- */
+ *
+ * out == NULL selects ACCUMULATE mode: nothing is finalised; every workgroup adds its partial sums
+ * {loss_b, top-1 % of the batch, sum pi*l, hits} to its own record in the workspace (no atomics),
+ * so a whole epoch of mini-batches costs one launch each, and rlvi_epoch_end_f32 (or
+ * rlvi_mstep_reduce_f32) reduces and clears the records.  A call WITH `out` overwrites and then
+ * clears the records it used, so do not interleave it with an accumulate sequence.
+ */
 int rlvi_mstep_fwd_bwd_f32(const float *logits, int64_t ld, const int64_t *labels,
                            const int64_t *idx, const float *weights, float *residuals,
                            int64_t N, int64_t B, int64_t C, float inv_scale,
@@ -74,6 +80,10 @@ int rlvi_mstep_fwd_bwd_bf16(const uint16_t *logits, int64_t ld, const int64_t *l
                             int64_t N, int64_t B, int64_t C, float inv_scale,
                             uint16_t *grad_logits, int64_t ldg, float *out, void *ws,
                             void *stream);
+
+/* out[4] = scale * {sum loss_b, sum top-1 %_b}, sum pi*l, hits over the accumulated batches;
+ * clears the records (scale = 1/batches gives the reference's train_acc, train_rlvi.py:105). */
+int rlvi_mstep_reduce_f32(float *out, double scale, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * E-step, deep-learning variant, in place on both vectors.
@@ -85,6 +95,17 @@ int rlvi_mstep_fwd_bwd_bf16(const uint16_t *logits, int64_t ld, const int64_t *l
  * ------------------------------------------------------------------------------------- */
 int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol, int maxiter,
                         int32_t *out_iters, float *trace, void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * End of an epoch in one call, replaces train_rlvi.py:99-105: update_sample_weights over all N
+ * samples; if `overfit`, *thr_inout = max(*thr_inout, criterion) and the truncation; and, if
+ * out != NULL, the epoch's M-step scalars reduced from the accumulate-mode records by an extra
+ * workgroup of the same launch: out[1] = mean over `batches` of the per-batch top-1 percentage
+ * (= train_acc of :105), out[0] = mean batch loss.
+ * ------------------------------------------------------------------------------------- */
+int rlvi_epoch_end_f32(float *residuals, float *weights, int64_t N, float tol, int maxiter,
+                       int overfit, float alpha, float *thr_inout, int64_t batches, float *out,
+                       int32_t *out_iters, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Type-II-error threshold, replaces false_negative_criterion(weights, alpha),

@@ -27,7 +27,10 @@ SIGNATURES = {
                                       _vp, _i64, _vp, _vp, _vp]),
     "rlvi_mstep_fwd_bwd_bf16": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                        _vp, _i64, _vp, _vp, _vp]),
+    "rlvi_mstep_reduce_f32": (_int, [_vp, _f64, _vp, _vp]),
     "rlvi_estep_deep_f32": (_int, [_vp, _vp, _i64, _f32, _int, _vp, _vp, _vp, _vp]),
+    "rlvi_epoch_end_f32": (_int, [_vp, _vp, _i64, _f32, _int, _int, _f32, _vp, _i64, _vp, _vp,
+                                  _vp, _vp]),
     "rlvi_fn_threshold_f32": (_int, [_vp, _i64, _f32, _vp, _vp, _vp]),
     "rlvi_threshold_truncate_f32": (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "rlvi_truncate_f32": (_int, [_vp, _i64, _vp, _vp, _vp]),

@@ -132,7 +132,8 @@ extern "C" int rlvi_linreg_losses_f64(const double *X, const double *y, const do
     if (!X || !y || !theta || !w || !losses || !ws) return RLVI_E_NULL;
     if (n <= 0 || d <= 0) return RLVI_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF);
+    // scratch region (NOT the M-step records, which must stay zero between epochs)
+    double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
     int nb = (int)((n + 3) / 4);
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(linreg_resid_kernel, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d,

@@ -31,10 +31,20 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
                                                             F *__restrict__ wts, int64_t N,
                                                             F tol, int maxiter,
                                                             int32_t *__restrict__ out_iters,
-                                                            F *__restrict__ trace, void *ws) {
+                                                            F *__restrict__ trace, void *ws,
+                                                            float *__restrict__ mstep_out,
+                                                            double mstep_scale) {
+    // epoch end: one extra workgroup (the last block, on a CU of its own) reduces and clears the
+    // M-step partial records of the epoch while the others run the fixed point
+    const int nwg = (int)gridDim.x - (mstep_out != nullptr ? 1 : 0);
+    if ((int)blockIdx.x == nwg) {
+        double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF);
+        reduce_partials(part, MSTEP_MAX_BLOCKS, mstep_scale, mstep_out, true, ESTEP_BLOCK);
+        return;
+    }
     Coop<ESTEP_BLOCK> co;
-    co.init(ws);
-    const int64_t gstride = (int64_t)gridDim.x * ESTEP_BLOCK;
+    co.init(ws, nwg);
+    const int64_t gstride = (int64_t)nwg * ESTEP_BLOCK;
     const int64_t i0 = (int64_t)blockIdx.x * ESTEP_BLOCK + threadIdx.x;
 
     // this thread's elements are i0 + j*gstride, j < cnt (a prefix of 0..E-1)
@@ -143,14 +153,16 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
 // G = ceil(N / (1024 E)) within one workgroup per CU; E = 8 (8192 samples per CU) by default.
 template <typename F, int VAR>
 static int launch_estep(F *res, F *wts, int64_t N, F tol, int maxiter, int32_t *out_iters,
-                        F *trace, void *ws, hipStream_t st) {
+                        F *trace, void *ws, hipStream_t st, float *mstep_out = nullptr,
+                        double mstep_scale = 1.0) {
     const int64_t per = ESTEP_BLOCK;
     auto groups = [&](int e) { return (N + per * e - 1) / (per * e); };
 #define RLVI_LAUNCH(E_)                                                                          \
     do {                                                                                         \
-        hipLaunchKernelGGL((estep_kernel<F, VAR, E_>), dim3((unsigned)groups(E_)),               \
+        hipLaunchKernelGGL((estep_kernel<F, VAR, E_>),                                           \
+                           dim3((unsigned)groups(E_) + (mstep_out != nullptr ? 1u : 0u)),        \
                            dim3(ESTEP_BLOCK), 0, st, res, wts, N, tol, maxiter, out_iters,       \
-                           trace, ws);                                                           \
+                           trace, ws, mstep_out, mstep_scale);                                   \
         return (int)hipGetLastError();                                                           \
     } while (0)
     if (N <= per * 4) RLVI_LAUNCH(4);
@@ -196,4 +208,24 @@ extern "C" int rlvi_update_weights_online_f64(const double *losses, int64_t n, d
     return launch_estep<double, VAR_ONLINE>(const_cast<double *>(losses), out, n, tol, maxiter,
                                             out_iters, nullptr, ws,
                                             static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------
+// End of a train_rlvi epoch (train_rlvi.py:99-105): E-step over all N samples, optional
+// truncation, and the epoch's M-step scalars (sum over the accumulate-mode M-step calls since
+// the last epoch end, scaled by 1/batches: out[1] is the reference's train_acc in percent).
+// ---------------------------------------------------------------------------------------
+extern "C" int rlvi_epoch_end_f32(float *residuals, float *weights, int64_t N, float tol,
+                                  int maxiter, int overfit, float alpha, float *thr_inout,
+                                  int64_t batches, float *out, int32_t *out_iters, void *ws,
+                                  void *stream) {
+    if (!residuals || !weights || !ws || (overfit && !thr_inout)) return RLVI_E_NULL;
+    if (N <= 0 || maxiter < 0 || batches < 0) return RLVI_E_SHAPE;
+    if (((uintptr_t)residuals & 3) || ((uintptr_t)weights & 3) || ((uintptr_t)ws & 255))
+        return RLVI_E_ALIGN;
+    int rc = launch_estep<float, VAR_DEEP>(residuals, weights, N, tol, maxiter, out_iters, nullptr,
+                                           ws, static_cast<hipStream_t>(stream), out,
+                                           batches > 0 ? 1.0 / (double)batches : 1.0);
+    if (rc || !overfit) return rc;
+    return rlvi_threshold_truncate_f32(weights, N, alpha, thr_inout, nullptr, nullptr, ws, stream);
 }

@@ -148,6 +148,17 @@ __device__ __forceinline__ float mexp(float x) {
 #endif
 }
 
+// Per-block partial record.  accum == 0: overwrite (a finalize launch follows); accum == 1: add
+// to what earlier mini-batches of this epoch left there (rlvi_epoch_end_f32 reduces and clears).
+// Every block owns its record, so there are no atomics and the sums are order-deterministic.
+__device__ __forceinline__ void write_partial(double *part, double ta, double th, float inv_scale,
+                                              double inv_rows100, int accum) {
+    double *p = part + (size_t)PART_STRIDE * blockIdx.x;
+    const double v0 = ta * (double)inv_scale, v1 = th * inv_rows100;
+    if (accum) { p[0] += v0; p[1] += v1; p[2] += ta; p[3] += th; }
+    else { p[0] = v0; p[1] = v1; p[2] = ta; p[3] = th; }
+}
+
 // A row is owned by G consecutive lanes; lane g holds the vectors k*G+g, k < kact <= KMAX, so one
 // load instruction reads G*V contiguous elements of each of the wave's 64/G rows and a lane
 // amortises the (short) lane-group reductions over up to KMAX*V elements.
@@ -156,7 +167,8 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
     const T *__restrict__ logits, int64_t ld, const int64_t *__restrict__ labels,
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
     float *__restrict__ residuals, int64_t N, int64_t B, int C, int kact, float inv_scale,
-    T *__restrict__ grad, int64_t ldg, double *__restrict__ part, int32_t *__restrict__ status) {
+    T *__restrict__ grad, int64_t ldg, double *__restrict__ part, int32_t *__restrict__ status,
+    int accum, double inv_rows100) {
     constexpr int R = WAVE / G;  // rows per wave
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
@@ -270,8 +282,7 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
         double ta = 0.0, th = 0.0;
 #pragma unroll
         for (int w = 0; w < MSTEP_WAVES; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
-        part[2 * blockIdx.x] = ta;
-        part[2 * blockIdx.x + 1] = th;
+        write_partial(part, ta, th, inv_scale, inv_rows100, accum);
     }
 }
 
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_tile_kernel(
     const T *__restrict__ logits, const int64_t *__restrict__ labels,
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
     float *__restrict__ residuals, int64_t N, int64_t B, int C, int kact, float inv_scale,
-    T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status) {
+    T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status, int accum,
+    double inv_rows100) {
     constexpr int TR = MSTEP_THREADS / G;          // rows per tile
     constexpr int R = WAVE / G;                    // rows per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -473,32 +485,14 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_tile_kernel(
         double ta = 0.0, th = 0.0;
 #pragma unroll
         for (int w = 0; w < MSTEP_WAVES; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
-        part[2 * blockIdx.x] = ta;
-        part[2 * blockIdx.x + 1] = th;
+        write_partial(part, ta, th, inv_scale, inv_rows100, accum);
     }
 }
 
-// Sums the per-block partials in a fixed order and writes the four output scalars.
-__global__ __launch_bounds__(256) void mstep_finalize_kernel(const double *__restrict__ part,
-                                                             int nblocks, float inv_scale,
-                                                             double inv_rows100,
-                                                             float *__restrict__ out) {
-    double a = 0.0, h = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { a += part[2 * i]; h += part[2 * i + 1]; }
-    a = wave_sum(a);
-    h = wave_sum(h);
-    __shared__ double sh[8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = h; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0.0, th = 0.0;
-        for (int w = 0; w < 4; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
-        out[0] = (float)(ta * (double)inv_scale);
-        out[1] = (float)th * (float)inv_rows100;
-        out[2] = (float)ta;
-        out[3] = (float)th;
-    }
+__global__ __launch_bounds__(256) void mstep_finalize_kernel(double *__restrict__ part, int nblocks,
+                                                             double scale, float *__restrict__ out,
+                                                             int clear) {
+    reduce_partials(part, nblocks, scale, out, clear != 0, 256);
 }
 
 static int env_int(const char *name, int dflt) {
@@ -518,6 +512,8 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
     char *base = static_cast<char *>(ws);
     double *part = reinterpret_cast<double *>(base + WS_PART_OFF);
     int32_t *status = reinterpret_cast<int32_t *>(base);
+    const int accum = out == nullptr ? 1 : 0;       // no `out`: accumulate for rlvi_epoch_end_f32
+    const double inv_rows100 = 100.0 / (double)B;
     const size_t tile_bytes = (size_t)TR * C * sizeof(T);
     const bool dense = ld == C && (grad == nullptr || ldg == C) && tile_bytes % 16 == 0 &&
                        ((uintptr_t)logits % 16) == 0 && ((uintptr_t)grad % 16) == 0 &&
@@ -530,7 +526,7 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         const size_t lds = tile_bytes + (size_t)TR * 16 + 16;
         hipLaunchKernelGGL((mstep_tile_kernel<T, V, G, KMAX>), dim3((unsigned)nb),
                            dim3(MSTEP_THREADS), lds, st, logits, labels, idx, weights, residuals,
-                           N, B, C, kact, inv_scale, grad, part, status);
+                           N, B, C, kact, inv_scale, grad, part, status, accum, inv_rows100);
     } else {
         const int64_t rows_per_block = (int64_t)MSTEP_WAVES * R;
         nb = (B + rows_per_block - 1) / rows_per_block;
@@ -539,14 +535,13 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL((mstep_kernel<T, V, G, KMAX>), dim3((unsigned)nb), dim3(MSTEP_THREADS),
                            0, st, logits, ld, labels, idx, weights, residuals, N, B, C, kact,
-                           inv_scale, grad, ldg, part, status);
+                           inv_scale, grad, ldg, part, status, accum, inv_rows100);
     }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, inv_scale,
-                       100.0 / (double)B, out);
-    e = hipGetLastError();
-    return (int)e;
+    if (e != hipSuccess || out == nullptr) return (int)e;
+    // the finalize pass clears what it read: records are all-zero outside an accumulate sequence
+    hipLaunchKernelGGL(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 1.0, out, 1);
+    return (int)hipGetLastError();
 }
 
 // Picks the lane group: the smallest G whose lanes need at most 8 vectors each (so the short
@@ -588,7 +583,7 @@ template <typename T>
 static int mstep_entry(const T *logits, int64_t ld, const int64_t *labels, const int64_t *idx,
                        const float *weights, float *residuals, int64_t N, int64_t B, int64_t C,
                        float inv_scale, T *grad, int64_t ldg, float *out, void *ws, void *stream) {
-    if (!logits || !labels || !weights || !out || !ws) return RLVI_E_NULL;
+    if (!logits || !labels || !weights || !ws) return RLVI_E_NULL;
     if (B <= 0 || C <= 0 || N <= 0 || ld < C || (grad && ldg < C)) return RLVI_E_SHAPE;
     if (C > (1 << 20)) return RLVI_E_LIMIT;
     if (((uintptr_t)labels & 7) || ((uintptr_t)idx & 7) || ((uintptr_t)weights & 3) ||
@@ -638,4 +633,13 @@ extern "C" int rlvi_mstep_fwd_bwd_bf16(const uint16_t *logits, int64_t ld, const
                                        void *stream) {
     return rlvi::mstep_entry<uint16_t>(logits, ld, labels, idx, weights, residuals, N, B, C,
                                        inv_scale, grad_logits, ldg, out, ws, stream);
+}
+
+// Reduce (and clear) the partial records that accumulate-mode M-step calls left in the workspace.
+extern "C" int rlvi_mstep_reduce_f32(float *out, double scale, void *ws, void *stream) {
+    if (!out || !ws) return RLVI_E_NULL;
+    double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + rlvi::WS_PART_OFF);
+    hipLaunchKernelGGL(rlvi::mstep_finalize_kernel, dim3(1), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), part, rlvi::MSTEP_MAX_BLOCKS, scale, out, 1);
+    return (int)hipGetLastError();
 }

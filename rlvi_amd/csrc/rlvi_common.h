@@ -27,8 +27,9 @@ constexpr size_t WS_XCHG_OFF = 1024;
 constexpr int XCHG_GRANULES = 4;                                        // per workgroup
 constexpr size_t WS_XCHG_BYTES = 2ull * MAX_COOP_WG * XCHG_GRANULES * 8; // 2 parities, 16 KiB
 constexpr size_t WS_PART_OFF = WS_XCHG_OFF + WS_XCHG_BYTES;
-constexpr int MSTEP_MAX_BLOCKS = 2048;
-constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * 2 * 8;      // {sum pi*l, hits} per block
+constexpr int MSTEP_MAX_BLOCKS = 1024;
+constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
+constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
 constexpr size_t WS_SCRATCH_OFF = WS_PART_OFF + WS_PART_BYTES;
 
 __host__ __device__ inline size_t ws_bytes_for(int64_t max_n, int64_t max_b) {
@@ -133,6 +134,38 @@ template <int G>
 __device__ __forceinline__ float group_sum(float v) { return group_allreduce<G>(v, FAdd()); }
 template <int G>
 __device__ __forceinline__ int group_min_i(int v) { return group_allreduce<G>(v, FMin()); }
+
+// Sums the per-block partial records in a fixed order and writes the four output scalars
+// (scaled by `scale`: 1 for a single batch, 1/batches for an epoch); optionally clears them.
+__device__ __forceinline__ void reduce_partials(double *__restrict__ part, int nblocks, double scale,
+                                                float *__restrict__ out, bool clear, int nthreads) {
+    double a[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nblocks; i += nthreads) {
+#pragma unroll
+        for (int c = 0; c < PART_STRIDE; ++c) {
+            a[c] += part[(size_t)PART_STRIDE * i + c];
+            if (clear) part[(size_t)PART_STRIDE * i + c] = 0.0;
+        }
+    }
+    __shared__ double sh[16 * PART_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < PART_STRIDE; ++c) {
+        a[c] = wave_sum(a[c]);
+        if (lane == 0) sh[wave * PART_STRIDE + c] = a[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < nthreads / 64; ++w)
+#pragma unroll
+            for (int c = 0; c < PART_STRIDE; ++c) t[c] += sh[w * PART_STRIDE + c];
+        out[0] = (float)(t[0] * scale);
+        out[1] = (float)(t[1] * scale);
+        out[2] = (float)t[2];
+        out[3] = (float)t[3];
+    }
+}
 
 // Order-preserving key of an fp32 value (ascending value <=> ascending unsigned key).
 __device__ __forceinline__ uint32_t f32_key(float f) {

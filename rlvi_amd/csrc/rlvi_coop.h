@@ -60,7 +60,8 @@ struct Coop {
 
     static constexpr int NW = BLOCK / WAVE;
 
-    __device__ __forceinline__ void init(void *ws) {
+    // nwg_ = number of exchanging workgroups (blocks 0..nwg_-1 of the grid)
+    __device__ __forceinline__ void init(void *ws, int nwg_) {
         char *base = static_cast<char *>(ws);
         WsHeader *hdr = reinterpret_cast<WsHeader *>(base);
         slots = (gu64 *)(reinterpret_cast<unsigned long long *>(base + WS_XCHG_OFF));
@@ -70,7 +71,7 @@ struct Coop {
         tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                 __HIP_MEMORY_SCOPE_AGENT) + 1u;
         step = 0;
-        nwg = (int)gridDim.x;
+        nwg = nwg_;
         dead = false;
     }
 

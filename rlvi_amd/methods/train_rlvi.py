@@ -44,8 +44,7 @@ def train_rlvi(train_loader, model, optimizer,
     place.  Returns (train_acc, threshold); threshold comes back unchanged while `overfit` is
     False and as a 0-dim device tensor once truncation has run (as in the reference)."""
     train_total = 0
-    train_correct = torch.zeros((), dtype=torch.float32, device=weights.device)
-    out = torch.empty(4, dtype=torch.float32, device=weights.device)
+    ws = ops.workspace(weights.device, weights.shape[0], 0)
 
     for (images, labels, indexes) in train_loader:
         images = images.to(weights.device, non_blocking=True)
@@ -53,22 +52,21 @@ def train_rlvi(train_loader, model, optimizer,
         indexes = indexes.to(weights.device, non_blocking=True)
 
         logits = model(images)
-        # reference :85,:89-94 and the backward of :96 in one fused pass over the logits:
+        # reference :85,:89-94 and the backward of :96 in ONE fused launch over the logits:
         # top-1, per-sample CE, residuals[indexes] = loss, weights[indexes] gather, weighted
-        # mean and d(loss)/d(logits)
-        out, grad = ops.mstep_fwd_bwd(logits.detach(), labels, indexes, weights,
-                                      residuals.detach(), out=out)
+        # mean and d(loss)/d(logits); the batch scalars accumulate on the device
+        _, grad = ops.mstep_fwd_bwd(logits.detach(), labels, indexes, weights,
+                                    residuals.detach(), accumulate=True, ws=ws)
         train_total += 1
-        train_correct += out[1]
 
         optimizer.zero_grad()
         logits.backward(grad)          # == loss.backward() of the reference (:96)
         optimizer.step()
 
-    update_sample_weights(residuals, weights)
-    if overfit:
-        # Regularization: truncate samples with high probability of corruption (:100-103)
-        threshold, _, _ = ops.threshold_truncate(weights, threshold)
+    # reference :99-103 plus the reduction of the accumulated top-1 percentages (:86-87,:105):
+    # E-step, optional truncation and the epoch scalars in one cooperative launch (+ threshold)
+    threshold, out = ops.epoch_end(residuals.detach(), weights, overfit=overfit,
+                                   threshold=threshold, batches=train_total, ws=ws)
 
-    train_acc = float(train_correct) / float(train_total)
+    train_acc = float(out[1]) if train_total else float("nan")
     return train_acc, threshold

@@ -66,12 +66,14 @@ def workspace(device, n=0, b=0):
 
 
 def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_grad=True,
-                  out=None, grad=None, ws=None):
+                  out=None, grad=None, ws=None, accumulate=False):
     """One mini-batch of the M-step (train_rlvi.py:85-96 without model/optimizer).
 
     Scatters the per-sample NLL into `residuals[idx]`, gathers the lagged pi from
     `weights[idx]`, returns (out, grad) with out = fp32[4] device tensor
     {weighted mean loss, top-1 %, sum pi*l, hits} and grad = dL/dlogits (or None).
+    accumulate=True: ONE launch, no scalars now (out is None): the per-batch sums pile up in the
+    workspace until `epoch_end` / `mstep_reduce` collects them.
     """
     L = _lib.load()
     _require_gpu(logits, labels, idx, weights, residuals)
@@ -91,7 +93,9 @@ def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_
     if residuals is not None and (residuals.dtype != torch.float32 or not residuals.is_contiguous()):
         raise ValueError("residuals must be a contiguous fp32 vector (it is written in place)")
     N = weights.shape[0]
-    if out is None:
+    if accumulate:
+        out = None
+    elif out is None:
         out = torch.empty(4, dtype=torch.float32, device=logits.device)
     if want_grad and grad is None:
         grad = torch.empty((B, C), dtype=logits.dtype, device=logits.device)
@@ -121,6 +125,44 @@ def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None,
     rc = L.rlvi_estep_deep_f32(_ptr(residuals), _ptr(weights), N, float(tol), int(maxiter),
                                _ptr(iters), _ptr(trace), ws.ptr, _stream_ptr())
     _lib.check(rc, "rlvi_estep_deep_f32")
+
+
+def mstep_reduce(scale=1.0, out=None, ws=None, device=None):
+    """Collect (and clear) the records of accumulate-mode M-step calls -> out fp32[4]."""
+    L = _lib.load()
+    ws = ws or workspace(device or torch.cuda.current_device())
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=ws.buf.device)
+    _lib.check(L.rlvi_mstep_reduce_f32(_ptr(out), float(scale), ws.ptr, _stream_ptr()),
+               "rlvi_mstep_reduce_f32")
+    return out
+
+
+def epoch_end(residuals, weights, overfit=False, threshold=0, batches=0, tol=1e-3, maxiter=40,
+              alpha=0.05, out=None, iters=None, ws=None):
+    """train_rlvi.py:99-105 in one call: E-step over all samples, truncation when `overfit`, and
+    the epoch's M-step scalars (out[1] = train_acc in percent when batches > 0).
+
+    Returns (threshold, out): threshold is passed through unchanged while overfit is False, and
+    a 0-dim device tensor after truncation ran; out is None when batches == 0."""
+    L = _lib.load()
+    _require_gpu(residuals, weights)
+    for t in (residuals, weights):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1:
+            raise ValueError("residuals / weights must be contiguous 1-D fp32 tensors")
+    N = weights.shape[0]
+    ws = ws or workspace(weights.device, N, 0)
+    thr = None
+    if overfit:
+        thr = torch.as_tensor(threshold, dtype=torch.float32, device=weights.device).reshape(1).clone()
+    if batches > 0 and out is None:
+        out = torch.empty(4, dtype=torch.float32, device=weights.device)
+    rc = L.rlvi_epoch_end_f32(_ptr(residuals), _ptr(weights), N, float(tol), int(maxiter),
+                              1 if overfit else 0, float(alpha), _ptr(thr), int(batches),
+                              _ptr(out) if batches > 0 else None, _ptr(iters), ws.ptr,
+                              _stream_ptr())
+    _lib.check(rc, "rlvi_epoch_end_f32")
+    return (thr.reshape(()) if overfit else threshold), (out if batches > 0 else None)
 
 
 def fn_threshold(weights, alpha=0.05):

@@ -168,6 +168,44 @@ def test_mstep_bench_size_properties_and_oracle(gpu, oracle):
     assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
 
 
+def test_mstep_accumulate_and_epoch_end(gpu, oracle):
+    """Accumulate mode: three ragged mini-batches, one launch each, then rlvi_epoch_end_f32
+    (E-step + truncation + scalar reduction) == the reference's epoch tail (:99-105)."""
+    torch, ops, dev = gpu
+    N, C = 1000, 10
+    d = synth.mstep_inputs(N, C, N=N, seed=77)
+    order = np.random.default_rng(5).permutation(N)
+    res_t = torch.zeros(N, device=dev)
+    w_t = torch.from_numpy(d["weights"].copy()).to(dev)
+    res_o, w_o = np.zeros(N, np.float32), d["weights"].copy()
+    ws = ops.Workspace(dev, N, N)
+    precs, losses = [], []
+    for lo, hi in ((0, 400), (400, 800), (800, 1000)):
+        rows = order[lo:hi]
+        z, y = d["logits"][rows], d["labels"][rows]
+        _, g = ops.mstep_fwd_bwd(torch.from_numpy(z).to(dev), torch.from_numpy(y).to(dev),
+                                 torch.from_numpy(rows).to(dev), w_t, res_t, accumulate=True, ws=ws)
+        ref = oracle.mstep(z, y, rows, w_o, res_o)
+        precs.append(float(ref["prec1"]))
+        losses.append(float(ref["loss"]))
+        assert np.abs(g.cpu().numpy().astype(np.float64) - ref["grad"]).max() <= 1e-6
+    thr, out = ops.epoch_end(res_t, w_t, overfit=True, threshold=0, batches=3, ws=ws)
+    torch.cuda.synchronize()
+    oracle.update_sample_weights(res_o, w_o)
+    thr_o = oracle.false_negative_criterion(w_o)
+    oracle.truncate(w_o, thr_o)
+    assert float(out[1]) == pytest.approx(np.mean(precs), abs=1e-4)
+    assert float(out[0]) == pytest.approx(np.mean(losses), rel=1e-5)
+    assert abs(float(thr) - float(thr_o)) <= REL * float(thr_o)
+    rel, small = rel_pi(w_t.cpu().numpy(), w_o)
+    assert rel <= REL and small <= 1e-7
+    assert np.array_equal(w_t.cpu().numpy() == 0, w_o == 0)
+    # the records were cleared: a second reduction returns zeros
+    z4 = ops.mstep_reduce(ws=ws)
+    assert float(z4.abs().sum()) == 0.0
+    assert ws.status() == 0
+
+
 # ------------------------------------------------------------------------------ E-step
 @pytest.mark.parametrize("key", g1_cases())
 def test_estep_threshold_mask_golden(key, golden, gpu, oracle):

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 from rlvi_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="mstep", choices=["mstep", "estep", "thr", "fused", "mstep_fwd"])
+ap.add_argument("--what", default="mstep", choices=["mstep", "mstep_out", "estep", "thr", "fused", "mstep_fwd", "step"])
 ap.add_argument("--rows", type=int, default=65536)
 ap.add_argument("--classes", type=int, default=100)
 ap.add_argument("--n", type=int, default=0, help="E-step / threshold vector length (default rows)")
@@ -49,7 +49,12 @@ with torch.cuda.stream(side):
     def leg(i):
         r = i % bench.ROTATE
         if a.what == "mstep":
+            ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, grad=grads[r], ws=ws, accumulate=True)
+        elif a.what == "mstep_out":
             ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, out=out, grad=grads[r], ws=ws)
+        elif a.what == "step":
+            ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, grad=grads[r], ws=ws, accumulate=True)
+            ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
         elif a.what == "mstep_fwd":
             ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, out=out, want_grad=False, ws=ws)
         elif a.what == "estep":
@@ -76,10 +81,10 @@ with torch.cuda.stream(side):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / a.steps * 1e3)
     extra = ""
-    if a.what in ("mstep", "mstep_fwd"):
+    if a.what in ("mstep", "mstep_fwd", "mstep_out"):
         s = 2 if a.dtype == "bf16" else 4
-        byt = B * ((2 if a.what == "mstep" else 1) * C * s + 24)
+        byt = B * ((1 if a.what == "mstep_fwd" else 2) * C * s + 24)
         extra = f" {byt / best / 1e3:8.1f} GB/s  frac {byt / best / 1e3 / 8000:.3f}"
-    if a.what in ("estep", "fused"):
+    if a.what in ("estep", "fused", "step"):
         extra = f" iters {int(iters)}"
     print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
