@@ -9,13 +9,20 @@
 // 32-byte record exchange of rlvi_coop.h ({sum pi, sum (pi'-pi)^2} as doubles).  Sums are
 // accumulated in fp64 in a fixed order, so the result is deterministic and every workgroup takes
 // the same stop decision.  Latency-bound: N*4 B <= a few MB; report us and iterations, not GB/s.
+#include <stdlib.h>
+
 #include "rlvi_coop.h"
 
 namespace rlvi {
 
 enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
 
-constexpr int ESTEP_BLOCK = 1024;
+
+// t/(1+t) etc.: fp32 uses v_rcp_f32 (1 ulp) + multiply instead of the ~15-instruction IEEE
+// division sequence: <= 2 ulp on pi, two orders of magnitude inside the 1e-5 parity budget, and
+// the division is the bulk of the per-iteration arithmetic.  fp64 keeps the exact division.
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double fdiv(double a, double b) { return a / b; }
 
 template <typename F>
 __device__ __forceinline__ F fexp(F x);
@@ -26,7 +33,7 @@ __device__ __forceinline__ double fexp<double>(double x) { return exp(x); }
 
 // in : deep: residuals (in/out, min-shifted), weights (in/out)
 //      std/online: losses (read only), out (write only)
-template <typename F, int VAR, int E>
+template <typename F, int VAR, int E, int ESTEP_BLOCK>
 __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
                                                             F *__restrict__ wts, int64_t N,
                                                             F tol, int maxiter,
@@ -91,23 +98,27 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
     else ratio = (F)(0.5 / (1.0 - 0.5));
 
     int it = 0;
+    F ratio_used = ratio;     // the ratio the latest pi was computed with
     while (it < maxiter) {
-        double sse = 0.0, sum = 0.0;
+        ratio_used = ratio;
+        // per-thread partial sums in the working precision (E <= 32 terms), fp64 across threads
+        F sse_t = (F)0, sum_t = (F)0;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             F nw;
             if (VAR == VAR_STD) {
-                nw = e[j] / (ratio + e[j]);           // rlvi.py:15
+                nw = fdiv(e[j], ratio + e[j]);        // rlvi.py:15
             } else {
                 const F t = ratio * e[j];             // train_rlvi.py:32 / main.py:52
-                nw = t / ((F)1 + t);
+                nw = fdiv(t, (F)1 + t);
             }
             nw = ok_(j) ? nw : (F)0;
             const F d = nw - w[j];
-            sse += (double)(d * d);
-            sum += (double)nw;
+            sse_t += d * d;
+            sum_t += nw;
             w[j] = nw;
         }
+        double sse = (double)sse_t, sum = (double)sum_t;
         co.template allreduce2<OpSum, OpSum>(sse, sum);
         const F err = (F)sqrt(sse);                   // ||new - weights||_2
         const F avg = (F)sum / (F)N;                  // mean(weights)
@@ -130,9 +141,16 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
 #pragma unroll
         for (int j = 0; j < E; ++j)
             if (ok_(j)) mx = w[j] > mx ? w[j] : mx;
-        double a = (double)mx, b = 0.0;
-        co.template allreduce2<OpMax, OpSum>(a, b);
-        mx = (F)a;
+        if (VAR == VAR_DEEP && it > 0) {
+            // pi is increasing in e and the min-shifted residual 0 gives e = 1 exactly, so the
+            // maximum is the value every thread can compute alone -- no exchange
+            const F t1 = ratio_used * (F)1;
+            mx = t1 / ((F)1 + t1);
+        } else {
+            double a = (double)mx, b = 0.0;
+            co.template allreduce2<OpMax, OpSum>(a, b);
+            mx = (F)a;
+        }
         if (VAR == VAR_ONLINE) mx = mx * (F)N;        // new /= max(new)*len(new)  (main.py:57)
 #pragma unroll
         for (int j = 0; j < E; ++j)
@@ -149,26 +167,37 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
 #undef ok_
 }
 
-// Workgroup count / elements per thread for N samples: the smallest E in {4,8,16,32} that keeps
-// G = ceil(N / (1024 E)) within one workgroup per CU; E = 8 (8192 samples per CU) by default.
+// Geometry: per iteration a workgroup pays (i) E elements per thread of arithmetic, (ii) a
+// two-stage fp64 reduction whose second stage grows with the wave count, (iii) one record exchange.
+// 256-thread workgroups (4 waves) with E = 8 (2048 samples per CU) measured fastest up to 63 groups; larger
+// vectors fall back to 1024-thread workgroups so that G stays within one workgroup per CU.
 template <typename F, int VAR>
 static int launch_estep(F *res, F *wts, int64_t N, F tol, int maxiter, int32_t *out_iters,
                         F *trace, void *ws, hipStream_t st, float *mstep_out = nullptr,
                         double mstep_scale = 1.0) {
-    const int64_t per = ESTEP_BLOCK;
-    auto groups = [&](int e) { return (N + per * e - 1) / (per * e); };
-#define RLVI_LAUNCH(E_)                                                                          \
+    static const int force_e = getenv("RLVI_ESTEP_E") ? atoi(getenv("RLVI_ESTEP_E")) : 0;
+    static const int force_b = getenv("RLVI_ESTEP_BLOCK") ? atoi(getenv("RLVI_ESTEP_BLOCK")) : 0;
+    auto groups = [&](int64_t blk, int e) { return (N + blk * e - 1) / (blk * e); };
+#define RLVI_LAUNCH(E_, B_)                                                                      \
     do {                                                                                         \
-        hipLaunchKernelGGL((estep_kernel<F, VAR, E_>),                                           \
-                           dim3((unsigned)groups(E_) + (mstep_out != nullptr ? 1u : 0u)),        \
-                           dim3(ESTEP_BLOCK), 0, st, res, wts, N, tol, maxiter, out_iters,       \
-                           trace, ws, mstep_out, mstep_scale);                                   \
+        hipLaunchKernelGGL((estep_kernel<F, VAR, E_, B_>),                                       \
+                           dim3((unsigned)groups(B_, E_) + (mstep_out != nullptr ? 1u : 0u)),    \
+                           dim3(B_), 0, st, res, wts, N, tol, maxiter, out_iters, trace, ws,     \
+                           mstep_out, mstep_scale);                                              \
         return (int)hipGetLastError();                                                           \
     } while (0)
-    if (N <= per * 4) RLVI_LAUNCH(4);
-    if (groups(8) <= MAX_COOP_WG) RLVI_LAUNCH(8);
-    if (groups(16) <= MAX_COOP_WG) RLVI_LAUNCH(16);
-    if (sizeof(F) == 4 && groups(32) <= MAX_COOP_WG) RLVI_LAUNCH(32);
+    const int lim = MAX_COOP_WG - 1;    // one CU stays free for the epoch-end reduction workgroup
+    if (force_b == 256 || force_b == 0) {
+        if ((force_e == 8 || !force_e) && groups(256, 8) <= lim / 4) RLVI_LAUNCH(8, 256);
+        if ((force_e == 16 || !force_e) && groups(256, 16) <= lim / 4) RLVI_LAUNCH(16, 256);
+        if (force_e == 32 && sizeof(F) == 4 && groups(256, 32) <= lim) RLVI_LAUNCH(16, 256);
+    }
+    if (force_e == 4 && groups(1024, 4) <= lim) RLVI_LAUNCH(4, 1024);
+    if (groups(1024, 8) <= lim) RLVI_LAUNCH(8, 1024);
+    if (groups(1024, 16) <= lim) RLVI_LAUNCH(16, 1024);
+    if constexpr (sizeof(F) == 4) {
+        if (groups(1024, 32) <= lim) RLVI_LAUNCH(32, 1024);
+    }
 #undef RLVI_LAUNCH
     return RLVI_E_LIMIT;
 }

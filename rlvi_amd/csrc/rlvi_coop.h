@@ -118,7 +118,7 @@ struct Coop {
                     unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0;
                     const bool mine = w < nwg;
                     gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG_GRANULES;
-                    for (;;) {
+                    for (unsigned spin = 0;; ++spin) {
                         bool ok = true;
                         if (mine) {
                             x0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -129,8 +129,11 @@ struct Coop {
                                  (uint32_t)(x2 >> 32) == tag && (uint32_t)(x3 >> 32) == tag;
                         }
                         if (__all(ok)) break;
-                        if (wall_clock64() - t0 > SPIN_BOUND_TICKS) { timeout = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
+                        // the wall clock is read only every 64 polls: keep the poll loop tight
+                        if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                            timeout = true;
+                            break;
+                        }
                     }
                     if (timeout) break;
                     if (mine) {
