@@ -385,6 +385,34 @@ def test_linreg_and_logistic_nll(gpu, oracle):
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-15)
 
 
+def test_standard_and_online_mirrors_golden(golden, gpu, oracle):
+    """numpy-in / numpy-out mirrors of standard-learning/rlvi.py and online-learning/main.py."""
+    from rlvi_amd import online, standard
+    g = golden("g5_standard")
+    k = "uw_bimodal_1000"
+    np.testing.assert_allclose(standard.update_weights(g[k + "/losses"]), g[k + "/w"], rtol=1e-11, atol=1e-300)
+    for (size, d) in ((40, 10), (1000, 20)):
+        k = f"linreg_{size}x{d}"
+        X, y = synth.linreg_data(size=size, d=d, eps=0.3, nu=2.5, seed=int(g[k + "/seed"]))
+        theta, w, outer = standard.linear_regression(X, y, return_info=True)
+        assert outer == int(g[k + "/outer"])
+        np.testing.assert_allclose(theta, g[k + "/theta"], rtol=1e-8)
+        np.testing.assert_allclose(w, g[k + "/w_last"], rtol=1e-6, atol=1e-300)
+    # logistic: the liblinear solve is third-party (sklearn version skew): theta to 1e-3
+    theta = standard.logistic_regression(g["logreg/X"].copy(), g["logreg/y"].copy())
+    np.testing.assert_allclose(theta, g["logreg/theta"], rtol=1e-3, atol=1e-4)
+    g6 = golden("g6_online")
+    np.testing.assert_allclose(online.update_weights_rlvi(g6["uw_bimodal_256/losses"]),
+                               g6["uw_bimodal_256/w"], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(online.cross_entropy(g6["ce/log_proba"], g6["ce/targets"]), g6["ce/out"])
+    # first mini-batch (classifier not fitted): residual log 2 everywhere (main.py:293)
+    np.testing.assert_allclose(online.rlvi_sample_weight(np.zeros((100, 3))), g6["uw_first/w"], rtol=1e-11)
+    Xl, wl, b = synth.logistic_data(256, 60)
+    np.testing.assert_allclose(online.residuals(Xl, wl, b), oracle.logistic_nll(Xl, wl, b), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(online.rlvi_sample_weight(Xl, wl, b),
+                               oracle.update_weights_rlvi(oracle.logistic_nll(Xl, wl, b)), rtol=1e-10)
+
+
 # ------------------------------------------------------------------------------ whole epochs
 def test_train_rlvi_epochs_golden(golden, gpu):
     """G4: the drop-in train_rlvi on the GPU against four reference epochs (overfit F,F,T,T)."""

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Runs on the GPU box: (1) rocprofv3 --kernel-trace --stats of the bench command, (2) two separate
+# PMC passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.  Usage: tools/profile_bench.sh <tag>
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/prof_$tag
+mkdir -p $out/trace $out/pmc_fetch $out/pmc_write
+ARGS="bench.py --profile-only --no-graph --steps 120 --warmup 12"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $ARGS > $out/trace/bench.json 2> $out/trace/err.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $ARGS > $out/pmc_fetch/bench.json 2> $out/pmc_fetch/err.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $ARGS > $out/pmc_write/bench.json 2> $out/pmc_write/err.log
+python3 tools/prof_summary.py $out $out/summary.md
+grep -E "rlvi::" $out/summary.md | cut -c1-160
