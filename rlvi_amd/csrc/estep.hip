@@ -17,6 +17,11 @@ namespace rlvi {
 
 enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
 
+// estep_traj.hip: the trajectory solver of the deep variant (returns 0 when not applicable)
+int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxiter,
+                          int32_t *out_iters, float *trace, void *ws, hipStream_t st,
+                          float *mstep_out, double mstep_scale, int *rc);
+
 
 // t/(1+t) etc.: fp32 uses v_rcp_f32 (1 ulp) + multiply instead of the ~15-instruction IEEE
 // division sequence: <= 2 ulp on pi, two orders of magnitude inside the 1e-5 parity budget, and
@@ -175,6 +180,12 @@ template <typename F, int VAR>
 static int launch_estep(F *res, F *wts, int64_t N, F tol, int maxiter, int32_t *out_iters,
                         F *trace, void *ws, hipStream_t st, float *mstep_out = nullptr,
                         double mstep_scale = 1.0) {
+    if constexpr (VAR == VAR_DEEP) {
+        int rc = 0;
+        if (try_launch_estep_traj(res, wts, N, tol, maxiter, out_iters, trace, ws, st, mstep_out,
+                                  mstep_scale, &rc))
+            return rc;
+    }
     static const int force_e = getenv("RLVI_ESTEP_E") ? atoi(getenv("RLVI_ESTEP_E")) : 0;
     static const int force_b = getenv("RLVI_ESTEP_BLOCK") ? atoi(getenv("RLVI_ESTEP_BLOCK")) : 0;
     auto groups = [&](int64_t blk, int e) { return (N + blk * e - 1) / (blk * e); };

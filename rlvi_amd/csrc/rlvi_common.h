@@ -26,7 +26,14 @@ constexpr size_t WS_HDR_BYTES = sizeof(WsHeader);                       // 768
 constexpr size_t WS_XCHG_OFF = 1024;
 constexpr int XCHG_GRANULES = 4;                                        // per workgroup
 constexpr size_t WS_XCHG_BYTES = 2ull * MAX_COOP_WG * XCHG_GRANULES * 8; // 2 parities, 16 KiB
-constexpr size_t WS_PART_OFF = WS_XCHG_OFF + WS_XCHG_BYTES;
+// second exchange region: 8-granule records (three doubles) of the trajectory E-step
+constexpr int XCHG2_GRANULES = 8;
+constexpr size_t WS_XCHG2_OFF = WS_XCHG_OFF + WS_XCHG_BYTES;
+constexpr size_t WS_XCHG2_BYTES = 2ull * MAX_COOP_WG * XCHG2_GRANULES * 8;     // 32 KiB
+// warm-start state of the trajectory E-step: {int64 n, int32 k, int32 pad, float nodes[64]}
+constexpr size_t WS_TRAJ_OFF = WS_XCHG2_OFF + WS_XCHG2_BYTES;
+constexpr size_t WS_TRAJ_BYTES = 512;
+constexpr size_t WS_PART_OFF = WS_TRAJ_OFF + WS_TRAJ_BYTES;
 constexpr int MSTEP_MAX_BLOCKS = 1024;
 constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
 constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;

@@ -279,18 +279,28 @@ def test_threshold_vs_oracle_sizes(N, gpu, oracle):
 
 @pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 50000, 65536, 75750, 200000, 600000])
 def test_estep_vs_oracle_sizes(N, gpu, oracle):
-    """Single-workgroup and cooperative multi-workgroup paths; deterministic across runs."""
+    """Iterative (N < 4096) and trajectory (N >= 4096, register and streaming slices) solvers.
+
+    Determinism: from the same workspace state two runs are bit-identical (fixed reduction
+    order -- this is also the race detector).  The trajectory solver warm-starts from the last
+    call's trajectory kept in the workspace; a different starting guess may move pi by one ulp
+    (the accepted trajectory is exact to 2.5e-9 relative, the fp32 roundings along it can fall
+    either way), so warm and cold results are compared at 5e-7, not bitwise."""
     torch, ops, dev = gpu
     r = synth.residual_vector("bimodal", N, seed=N)
     w0 = np.random.default_rng(N).random(N).astype(np.float32)
     outs = []
-    for _ in range(2):
+    for fresh in (True, True, False):
+        ws = ops.Workspace(dev, N, 0) if fresh else ws       # noqa: F821  (third run: warm state)
         rt, wt = torch.from_numpy(r.copy()).to(dev), torch.from_numpy(w0.copy()).to(dev)
         iters = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops.estep_deep(rt, wt, iters=iters)
+        ops.estep_deep(rt, wt, iters=iters, ws=ws)
         torch.cuda.synchronize()
+        assert ws.status() == 0
         outs.append((rt.cpu().numpy(), wt.cpu().numpy(), int(iters)))
     assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    assert outs[2][2] == outs[0][2]
+    np.testing.assert_allclose(outs[2][1], outs[0][1], rtol=5e-7, atol=1e-37)
     rr, ww = r.copy(), w0.copy()
     it, err, avg = oracle.update_sample_weights(rr, ww, trace=True)
     tie = np.min(np.abs(err - 1e-3)) < 1e-5 * 1e-3      # stop decision within rounding of tol
@@ -299,7 +309,30 @@ def test_estep_vs_oracle_sizes(N, gpu, oracle):
         rel, small = rel_pi(outs[0][1], ww)
         assert rel <= REL and small <= 1e-7
     assert np.array_equal(outs[0][0], rr)
-    assert dev_status(ops, dev) == 0
+
+
+def test_estep_trajectory_cold_warm_and_poor_guess(gpu, oracle):
+    """The trajectory solver must not depend on the quality of its starting guess: cold start,
+    warm start from the same data, and warm start from a very different vector of the same
+    length (a poor guess: more Newton rounds) all give the oracle's iteration count and pi."""
+    torch, ops, dev = gpu
+    N = 30000
+    ws = ops.Workspace(dev, N, 0)
+    seq = [("bimodal", 1), ("bimodal", 1), ("heavy", 2), ("equal", 3), ("exp", 4), ("zeros10", 5),
+           ("bimodal", 6)]
+    for kind, seed in seq:
+        r = synth.residual_vector(kind, N, seed=seed)
+        rt, wt = torch.from_numpy(r.copy()).to(dev), torch.ones(N, device=dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=iters, ws=ws)
+        rr, ww = r.copy(), np.ones(N, np.float32)
+        it, err, _ = oracle.update_sample_weights(rr, ww, trace=True)
+        if np.min(np.abs(err - 1e-3)) >= 1e-5 * 1e-3:
+            assert int(iters) == it, (kind, seed)
+        rel, small = rel_pi(wt.cpu().numpy(), ww)
+        assert rel <= REL and small <= 1e-7, (kind, seed)
+        assert np.array_equal(rt.cpu().numpy(), rr)
+    assert ws.status() == 0
 
 
 def test_estep_maxiter_cap_and_tol(gpu, oracle):

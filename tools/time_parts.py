@@ -87,4 +87,12 @@ with torch.cuda.stream(side):
         extra = f" {byt / best / 1e3:8.1f} GB/s  frac {byt / best / 1e3 / 8000:.3f}"
     if a.what in ("estep", "fused", "step"):
         extra = f" iters {int(iters)}"
+    if os.environ.get("RLVI_TJ_DEBUG"):
+        import numpy as np
+        from rlvi_amd import _lib
+        off = 1024 + 16384 + 32768 + 512 + 32768      # WS_SCRATCH_OFF (rlvi_common.h)
+        raw = ws.buf[off:off + 64 * 8].cpu().numpy().view(np.uint64)
+        n = int(raw[63])
+        st = raw[:n].astype(np.int64)
+        print("stamps (us since kernel start):", [round(float(x - st[0]) / 100.0, 2) for x in st])
     print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
