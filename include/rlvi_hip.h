@@ -41,6 +41,7 @@ extern "C" {
 
 #define RLVI_ST_RANGE   1  /* a label or index was out of range (row skipped)      */
 #define RLVI_ST_TIMEOUT 2  /* an inter-workgroup wait hit its bound (results invalid) */
+#define RLVI_ST_NOCONV  4  /* the trajectory E-step did not reach its fixed point (results invalid) */
 
 int rlvi_abi_version(void);
 const char *rlvi_error_string(int code);

@@ -35,91 +35,206 @@ constexpr float TJ_ACCEPT = 1e-6f;
 struct TrajState {
     long long n;
     int k;
-    int pad;
+    float shift;                 // min residual of the last call (guess of this call's shift)
     float nodes[TJ_MAXK];
 };
 
+constexpr int TJ_MAXS = 8;       // slices per node (one lane of the polling wave sweeps them)
+
 struct TjShared {
     double part[TJ_NW][3];
-    double rec[MAX_COOP_WG][3];
-    double tot[TJ_MAXK][3];
-    float nodes[2][TJ_MAXK];     // [round parity]: read the old nodes, write the corrected ones
+    double rec[MAX_COOP_WG][4];   // gathered records (wave 0 only)
+    float pmin[TJ_NW];
+    float nodes[TJ_MAXK];        // corrected trajectory of the latest round
     int dead;
     int res_it;
-    float res_delta, res_rfin;
+    float res_delta, res_rfin, res_min;
 };
 
-// All workgroups publish {a, b, c}; afterwards sh.rec[w][0..2] holds every workgroup's record.
-// Same protocol as rlvi_coop.h (self-tagged 8-byte granules, sc1 stores / loads, parity slots).
-__device__ __forceinline__ void tj_exchange(TjShared &sh, double a, double b, double c, gu64 *slots,
-                                            uint32_t tag, int step, int nwg, int32_t *status,
-                                            bool &dead) {
+// ---------------------------------------------------------------------------------------
+// One round's communication + the scalar recurrence, all on wave 0 (the other waves wait at the
+// closing barrier).  Workgroup b = k*S + s publishes {S, S', D, min} as 8 self-tagged granules;
+// lane k of wave 0 polls the S records of node k, so the per-node totals land in the lane that
+// runs node k's part of the recurrence: no LDS staging, no second reduction stage.
+// Protocol as in rlvi_coop.h (sc1 stores / loads, parity slots, tags from the workspace base).
+// ---------------------------------------------------------------------------------------
+struct TjRound {
+    float rn;         // node the sums were evaluated at (r-space), per lane
+    float scale;      // exp(min - shift): converts the evaluated nodes to r-space (round 0 only)
+};
+
+template <bool FIRST>
+__device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float fD, float fmin_,
+                                         gu64 *slots, uint32_t tag, int xstep, int K, int S,
+                                         int32_t *status, bool &dead, float rn_l, float shift,
+                                         float invN, float tol, float *trace, bool want_nodes,
+                                         unsigned long long *dbg = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
-    a = group_allreduce<WAVE>(a, FAdd());
-    b = group_allreduce<WAVE>(b, FAdd());
-    c = group_allreduce<WAVE>(c, FAdd());
-    if (lane == 0) { sh.part[wave][0] = a; sh.part[wave][1] = b; sh.part[wave][2] = c; }
+    double a = group_allreduce<WAVE>((double)fS, FAdd());
+    double b = group_allreduce<WAVE>((double)fP, FAdd());
+    double c = group_allreduce<WAVE>((double)fD, FAdd());
+    float mn = FIRST ? group_allreduce<WAVE>(fmin_, FMin()) : 0.0f;
+    if (lane == 0) {
+        sh.part[wave][0] = a; sh.part[wave][1] = b; sh.part[wave][2] = c;
+        if (FIRST) sh.pmin[wave] = mn;
+    }
     __syncthreads();
-    if (wave == 0) {
-        double t[3];
+    constexpr int NQ = FIRST ? 8 : 6;
+    constexpr int PER = MAX_COOP_WG / WAVE;          // polling waves (one record per lane each)
+    auto dbl = [](unsigned long long lo, unsigned long long hi) {
+        return __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
+    };
+    gu64 *buf = slots + (size_t)(xstep & 1) * MAX_COOP_WG * XCHG2_GRANULES;
+    const int nwg = K * S;
+    if (wave == 0 && !dead) {
+        double t[4];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            double v = lane < TJ_NW ? sh.part[lane][q] : 0.0;
+            const double v = lane < TJ_NW ? sh.part[lane][q] : 0.0;
             t[q] = group_allreduce<WAVE>(v, FAdd());
         }
-        gu64 *buf = slots + (size_t)(step & 1) * MAX_COOP_WG * XCHG2_GRANULES;
-        if (!dead) {
-            if (lane < 6) {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(t[lane >> 1]);
-                const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-                __hip_atomic_store(buf + (size_t)blockIdx.x * XCHG2_GRANULES + lane,
-                                   ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        t[3] = FIRST ? (double)group_allreduce<WAVE>(lane < TJ_NW ? sh.pmin[lane] : __builtin_inff(), FMin())
+                     : 0.0;
+        if (lane < 8) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(t[lane >> 1]);
+            const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+            __hip_atomic_store(buf + (size_t)blockIdx.x * XCHG2_GRANULES + lane,
+                               ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // waves 0..3 sweep 64 records each (one record per lane, all its granules in flight) into LDS
+    if (wave < PER && !dead) {
+        const int w = wave * WAVE + lane;
+        const bool mine = w < nwg;
+        gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG2_GRANULES;
+        const unsigned long long t0 = wall_clock64();
+        bool timeout = false;
+        unsigned long long x[NQ];
+        for (unsigned spin = 0;; ++spin) {
+            bool ok = true;
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    x[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) ok = ok && (uint32_t)(x[q] >> 32) == tag;
             }
-            const unsigned long long t0 = wall_clock64();
-            bool timeout = false;
-            // lane l owns records l, l+64, l+128, l+192: all of them are polled together
-            constexpr int PER = MAX_COOP_WG / WAVE;
-            unsigned long long x[PER][6];
-            for (unsigned spin = 0;; ++spin) {
-                bool ok = true;
-#pragma unroll
-                for (int u = 0; u < PER; ++u) {
-                    const int w = lane + u * WAVE;
-                    if (w < nwg) {
-                        gu64 *p = buf + (size_t)w * XCHG2_GRANULES;
-#pragma unroll
-                        for (int q = 0; q < 6; ++q)
-                            x[u][q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) ok = ok && (uint32_t)(x[u][q] >> 32) == tag;
-                    }
-                }
-                if (__all(ok)) break;
-                if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
-                    timeout = true;
-                    break;
-                }
-            }
-            if (!timeout) {
-#pragma unroll
-                for (int u = 0; u < PER; ++u) {
-                    const int w = lane + u * WAVE;
-                    if (w < nwg) {
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            sh.rec[w][q] = __longlong_as_double((long long)(
-                                ((x[u][2 * q + 1] & 0xFFFFFFFFull) << 32) | (x[u][2 * q] & 0xFFFFFFFFull)));
-                    }
-                }
-            }
-            if (__any(timeout)) {
-                dead = true;
-                if (lane == 0) atomicOr(status, RLVI_ST_TIMEOUT);
+            if (__all(ok)) break;
+            if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                timeout = true;
+                break;
             }
         }
-        if (lane == 0) sh.dead = dead ? 1 : 0;
+        if (timeout) {
+            if (lane == 0) { atomicOr(status, RLVI_ST_TIMEOUT); sh.dead = 1; }
+        } else if (mine) {
+#pragma unroll
+            for (int q = 0; q < NQ / 2; ++q) sh.rec[w][q] = dbl(x[2 * q], x[2 * q + 1]);
+        }
+    }
+    __syncthreads();
+    dead = dead || sh.dead != 0;
+    if (wave == 0) {
+        double tS = 0.0, tP = 0.0, tD = 0.0;
+        float gmin = __builtin_inff();
+        if (!dead && lane < K) {
+            for (int ss = 0; ss < S; ++ss) {              // fixed order over the slices
+                const int w = lane * S + ss;
+                tS += sh.rec[w][0];
+                tP += sh.rec[w][1];
+                tD += sh.rec[w][2];
+                if constexpr (FIRST) gmin = fminf(gmin, (float)sh.rec[w][3]);
+            }
+        }
+        const bool has = lane < K;
+        float scale = 1.0f;
+        if (FIRST) {
+            gmin = group_allreduce<WAVE>(gmin, FMin());
+            // the sums were taken with e' = exp(-(l - shift)) = e * exp(shift - min): in r-space the
+            // evaluated nodes are rn * exp(shift - min); not trustworthy if that factor is extreme
+            // or a sum overflowed
+            scale = expf(shift - gmin);
+        }
+        const float rn = rn_l * scale;
+        bool finite = has ? (tS == tS && tP == tP && tD == tD && tS < 1e300 && tD < 1e300 && tS > 0.0)
+                          : true;
+        const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
+        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+            if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tD); }
+            if (lane == 0) { dbg[102] = __ballot(finite); dbg[103] = __float_as_uint(scale); }
+        }
+
+        // lane-parallel: a0 = mean(pi) at the node, b = d mean / dr, err = ||new - old||_2
+        const float a0_l = has ? (float)tS * invN : 0.0f;                                // (:35)
+        const float b_l = has ? (float)(tP * (double)invN) : 0.0f;
+        const float err_l = has ? sqrtf((float)tD) : __builtin_inff();                   // (:33)
+        const unsigned long long stopmask = __ballot(has && err_l < tol);                // (:36)
+        const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : K;
+        const int steps = it_now + 2 < K ? it_now + 2 : K;      // a little lookahead
+        float r = (float)(0.95 / (1.0 - 0.95));
+        float rnew_l = rn;
+        float avg_l = 0.0f;
+        // serial chain; `step` is wave-uniform, so the per-node values come through v_readlane
+        // (SGPR lane select, no LDS):  avg = a0 + b (r - r'),  r <- avg / (1 - avg)
+#pragma unroll 1
+        for (int step = 0; step < steps; ++step) {
+            {
+                const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
+                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
+                const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
+                if (lane == step) rnew_l = r;
+                // damped step: the linearisation is trusted within +-50% of the node (S is concave
+                // in r, so the extrapolated mean stays positive); mean(pi) < 1
+                const float h = 0.5f * rns;
+                const float d = fmaxf(fminf(r - rns, h), -h);
+                const float avg = fminf(fmaf(bb, d, a0), 0.999999f);
+                if (lane == step) avg_l = avg;
+                r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-37f);              // (:31)
+            }
+        }
+        // nodes beyond the lookahead: a fresh geometric tail from the last corrected node
+        {
+            const float last = __shfl(rnew_l, steps - 1, WAVE);      // all lanes take part
+            if (has && lane >= steps) rnew_l = last * exp2f(-(float)(lane - steps + 1));
+        }
+        float d_l = (has && lane < it_now) ? fabsf(rnew_l - rn) * __builtin_amdgcn_rcpf(rn) : 0.0f;
+        float delta_w = group_allreduce<WAVE>(d_l, FMax());
+        // Early accept: with nodes off by delta the corrected r are good to 0.25 delta^2, and the
+        // errors (evaluated AT the nodes) to about delta*(r_k + r_{k-1})/|r_k - r_{k-1}| relative.
+        // If every stop test up to `it` clears tol by 8x that margin, the stop index cannot change
+        // any more, and neither can pi: no verification round needed.  (Not when the caller asked
+        // for the error trace: that wants the errors themselves.)
+        const float rp_l = __shfl_up(rn, 1, WAVE);
+        if (delta_w > TJ_ACCEPT && delta_w <= 1e-3f && trace == nullptr) {
+            float u = 0.0f;
+            if (has && lane < it_now && lane > 0) {
+                const float gap = fabsf(rn - rp_l);
+                u = 8.0f * delta_w * (rn + rp_l) * __builtin_amdgcn_rcpf(fmaxf(gap, 1e-30f));
+            }
+            if (lane == 0) u = 128.0f * delta_w;            // D_0 is taken against the caller's pi
+            const bool unsafe = has && lane < it_now && fabsf(err_l - tol) <= u * err_l;
+            if (__ballot(unsafe) == 0ull) delta_w = 0.0f;
+        }
+        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+            dbg[130 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
+            if (lane == 0) { dbg[128] = round_ok; dbg[129] = ((unsigned long long)it_now << 32) | __float_as_uint(delta_w); }
+        }
+        if (!round_ok) { delta_w = __builtin_inff(); rnew_l = rn_l; }   // keep the old guesses
+        if (has && want_nodes) sh.nodes[lane] = rnew_l;
+        if (trace != nullptr && blockIdx.x == 0 && lane < it_now && round_ok) {
+            trace[2 * lane] = err_l;
+            trace[2 * lane + 1] = avg_l;
+        }
+        const float rfin_w = __shfl(rnew_l, it_now - 1, WAVE);   // all lanes take part
+        if (lane == 0) {
+            sh.res_it = it_now;
+            sh.res_delta = delta_w;
+            sh.res_rfin = rfin_w;
+            if (FIRST) sh.res_min = gmin;
+            sh.dead = dead ? 1 : 0;
+        }
     }
     __syncthreads();
     dead = sh.dead != 0;
@@ -141,6 +256,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
         return;
     }
     __shared__ TjShared sh;
+    if (threadIdx.x == 0) sh.dead = 0;
     char *wsb = static_cast<char *>(ws);
     WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
     gu64 *slots = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG2_OFF));
@@ -151,14 +267,23 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
     bool dead = false;
 
     const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
     const int k = (int)blockIdx.x / S, s = (int)blockIdx.x - k * S;
     const int64_t L = (N + S - 1) / S;
     const int64_t lo = (int64_t)s * L;
     const int64_t hi = lo + L < N ? lo + L : N;
     constexpr int EE = E > 0 ? E : 1;
 
-    // ---- slice -> registers, local min
-    float e[EE], w0[EE];
+    // ---- warm-start state (read early: its latency hides behind the slice loads)
+    const bool warm = state->n == (long long)N && state->k == K;
+    const float shift = warm ? state->shift : 0.0f;     // guess of min(l); NLLs are >= 0
+    // node guesses in r-space: last call's trajectory, else geometric; lane j of every wave holds
+    // node j (wave 0 needs them all, the workgroup needs r_k and r_{k-1})
+    float rn_l = lane < K ? (warm ? state->nodes[lane] : 19.0f * exp2f(-(float)lane)) : 1.0f;
+    if (lane == 0) rn_l = (float)(0.95 / (1.0 - 0.95));
+
+    // ---- slice -> registers (raw residuals), local min
+    float e[EE];
     int cnt = 0;
     float mn = __builtin_inff();
     if (E > 0) {
@@ -167,59 +292,23 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
             const int64_t i = lo + tid + (int64_t)j * TJ_BLOCK;
             const bool ok = i < hi;
             e[j] = ok ? res[i] : __builtin_inff();
-            w0[j] = (ok && k == 0) ? wts[i] : 0.0f;     // caller's pi: only D_0 needs it
             if (ok) { cnt = j + 1; mn = fminf(mn, e[j]); }
         }
     } else {
         for (int64_t i = lo + tid; i < hi; i += TJ_BLOCK) mn = fminf(mn, res[i]);
     }
-    {
-        // min via the sum exchange: every workgroup gets all local minima and takes their min
-        double a = (double)group_allreduce<WAVE>(mn, FMin());
-        const int lane = tid & 63, wave = tid >> 6;
-        __shared__ float smin[TJ_NW];
-        if (lane == 0) smin[wave] = (float)a;
-        __syncthreads();
-        float bm = smin[0];
-#pragma unroll
-        for (int w = 1; w < TJ_NW; ++w) bm = fminf(bm, smin[w]);
-        // publish the block minimum once (thread 0's value after the wave butterfly: divide by 64
-        // lanes * 16 waves is avoided by sending it in slot a of lane 0 only)
-        double pa = (tid == 0) ? (double)bm : 0.0;
-        tj_exchange(sh, pa, 0.0, 0.0, slots, tag, xstep, nwg, &hdr->status, dead);
-        ++tag; ++xstep;
-        float g = __builtin_inff();
-        for (int w = tid & 63; w < nwg; w += WAVE) g = fminf(g, (float)sh.rec[w][0]);
-        mn = group_allreduce<WAVE>(g, FMin());
-    }
-    TJ_STAMP();   // after the min exchange
-    // residuals.sub_(min) (:27), e = exp(-residuals) (:28); node-0 workgroups store the shift
-    if (E > 0) {
-#pragma unroll
-        for (int j = 0; j < EE; ++j) {
-            const int64_t i = lo + tid + (int64_t)j * TJ_BLOCK;
-            const float l = e[j] - mn;
-            if (j < cnt && k == 0) res[i] = l;
-            e[j] = j < cnt ? expf(-l) : 0.0f;
-        }
-    }
-    // (streaming form: the slice is re-read unshifted every round; the shift is stored in the final
-    //  phase by the one workgroup that owns the element there, after everybody's last read)
-
-    // ---- initial nodes: last call's trajectory if it was for the same N and K, else geometric
-    const bool warm = state->n == (long long)N && state->k == K;
-    if (tid < K) sh.nodes[0][tid] = warm ? state->nodes[tid] : 19.0f * exp2f(-(float)tid);
-    __syncthreads();
-    float r_mine = sh.nodes[0][k];
-    float r_prev = k > 0 ? sh.nodes[0][k - 1] : 0.0f;
-    if (k == 0) r_mine = (float)(0.95 / (1.0 - 0.95));
-    __syncthreads();
+    TJ_STAMP();   // slice loaded
 
     const float invN = 1.0f / (float)N;
+    float r_mine = __shfl(rn_l, k, WAVE);
+    float r_prev = k > 0 ? __shfl(rn_l, k - 1, WAVE) : 0.0f;
+    float cshift = shift;        // shift the e values are currently computed with
+    bool e_ready = false;        // e[] holds exp(-(l - true min)) (after round 0)
     int it = K;
     float r_fin = r_mine;
-    int cur = 0;
-    for (int round = 0; round <= K; ++round) {
+    float gmin = 0.0f;
+    bool accepted = false;
+    for (int round = 0; round <= K + 1; ++round) {
         // ---- sums of this workgroup's node over its slice
         float fS = 0.0f, fP = 0.0f, fD = 0.0f;
         auto body = [&](float ev, float wv) {
@@ -227,7 +316,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
             const float inv = __builtin_amdgcn_rcpf(1.0f + t);
             const float f = t * inv;
             float fp;
-            if (k == 0) fp = wv;
+            if (k == 0) fp = wv;                           // caller's pi: D_0 (:33, first pass)
             else { const float tp = r_prev * ev; fp = tp * __builtin_amdgcn_rcpf(1.0f + tp); }
             const float d = f - fp;
             fS += f;
@@ -236,108 +325,57 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
         };
         if (E > 0) {
 #pragma unroll
-            for (int j = 0; j < EE; ++j)
-                if (j < cnt) body(e[j], w0[j]);
+            for (int j = 0; j < EE; ++j) {
+                if (j < cnt) {
+                    const float ev = e_ready ? e[j] : expf(-(e[j] - cshift));
+                    const float wv = k == 0 ? wts[lo + tid + (int64_t)j * TJ_BLOCK] : 0.0f;
+                    body(ev, wv);
+                }
+            }
         } else {
             for (int64_t i = lo + tid; i < hi; i += TJ_BLOCK)
-                body(expf(-(res[i] - mn)), k == 0 ? wts[i] : 0.0f);
+                body(expf(-(res[i] - cshift)), k == 0 ? wts[i] : 0.0f);
         }
         TJ_STAMP();   // sums done
-        tj_exchange(sh, (double)fS, (double)fP, (double)fD, slots, tag, xstep, nwg, &hdr->status, dead);
+        if (round == 0)
+            tj_round<true>(sh, fS, fP, fD, mn, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
+                           shift, invN, tol, trace, true, dbg);
+        else
+            tj_round<false>(sh, fS, fP, fD, 0.0f, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
+                            shift, invN, tol, trace, true);
         ++tag; ++xstep;
-        TJ_STAMP();   // exchange done
-        // ---- totals per node, fixed order over the slices
-        if (tid < K) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                double t = 0.0;
-                for (int ss = 0; ss < S; ++ss) t += sh.rec[tid * S + ss][q];
-                sh.tot[tid][q] = t;
-            }
-        }
-        __syncthreads();
-        // ---- scalar recurrence with the first-order correction: wave 0 only (redundant copies
-        // on all 16 waves would share the CU's issue slots); lane j holds node j's data, the
-        // serial chain reads it with v_readlane, everything else (errors, stop index, delta) is
-        // lane-parallel
-        if (tid < WAVE) {
-            const int lane = tid;
-            const bool has = lane < K;
-            const float rn_l = has ? sh.nodes[cur][lane] : 1.0f;
-            // lane-parallel: a0 = mean(pi) at the node, b = d mean / dr (fp32 from the fp64 totals)
-            const float a0_l = has ? (float)sh.tot[lane][0] * invN : 0.0f;          // (:35)
-            const float b_l = has ? (float)(sh.tot[lane][1] * (double)invN) : 0.0f;
-            const float err_l = has ? (float)sqrt(sh.tot[lane][2]) : __builtin_inff();   // (:33)
-            const unsigned long long stopmask = __ballot(has && err_l < tol);           // (:36)
-            const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : K;
-            const int steps = it_now + 2 < K ? it_now + 2 : K;      // a little lookahead
-            float r = (float)(0.95 / (1.0 - 0.95));
-            float rnew_l = rn_l;                                     // corrected node of this lane
-            float avg_l = 0.0f;
-            // serial chain, fully unrolled so that `step` is a literal (v_readlane, no LDS):
-            // avg = a0 + b (r - r'), r <- avg / (1 - avg): five dependent fp32 operations per step
-#pragma unroll
-            for (int step = 0; step < TJ_MAXK; ++step) {
-                if (step < steps) {
-                    const float rn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn_l), step));
-                    const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
-                    const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
-                    if (lane == step) rnew_l = r;
-                    // damped step: the linearisation is trusted within +-50% of the node (S is
-                    // concave in r, so the extrapolated mean stays positive); mean(pi) < 1
-                    const float h = 0.5f * rn;
-                    const float d = fmaxf(fminf(r - rn, h), -h);
-                    const float avg = fminf(fmaf(bb, d, a0), 0.999999f);
-                    if (lane == step) avg_l = avg;
-                    r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-37f);   // (:31)
-                }
-            }
-            // nodes beyond the lookahead: a fresh geometric tail from the last corrected node
-            if (has && lane >= steps) {
-                const float last = __shfl(rnew_l, steps - 1, WAVE);
-                rnew_l = last * exp2f(-(float)(lane - steps + 1));
-            }
-            float d_l = (has && lane < it_now) ? fabsf(rnew_l - rn_l) * __builtin_amdgcn_rcpf(rn_l) : 0.0f;
-            float delta_w = group_allreduce<WAVE>(d_l, FMax());
-            // Early accept: with nodes off by delta the corrected r are good to 0.25 delta^2, and
-            // the errors (evaluated AT the nodes) to about delta*(r_k + r_{k-1})/|r_k - r_{k-1}|
-            // relative.  If every stop test up to `it` clears tol by 8x that margin, the stop
-            // index cannot change any more, and neither can pi: no verification round needed.
-            // (Not when the caller asked for the error trace: that wants the errors themselves.)
-            if (delta_w > TJ_ACCEPT && delta_w <= 1e-3f && trace == nullptr) {
-                const float rp_l = __shfl_up(rn_l, 1, WAVE);
-                float u = 0.0f;
-                if (has && lane < it_now && lane > 0) {
-                    const float gap = fabsf(rn_l - rp_l);
-                    u = 8.0f * delta_w * (rn_l + rp_l) * __builtin_amdgcn_rcpf(fmaxf(gap, 1e-30f));
-                }
-                if (lane == 0) u = 128.0f * delta_w;       // D_0 is taken against the caller's pi
-                const bool unsafe = has && lane < it_now && fabsf(err_l - tol) <= u * err_l;
-                if (__ballot(unsafe) == 0ull) delta_w = 0.0f;
-            }
-            if (has) sh.nodes[cur ^ 1][lane] = rnew_l;
-            if (trace != nullptr && blockIdx.x == 0 && lane < it_now) {
-                trace[2 * lane] = err_l;
-                trace[2 * lane + 1] = avg_l;
-            }
-            const float rfin_w = __shfl(rnew_l, it_now - 1, WAVE);   // all lanes take part
-            if (lane == 0) {
-                sh.res_it = it_now;
-                sh.res_delta = delta_w;
-                sh.res_rfin = rfin_w;
-            }
-        }
-        __syncthreads();
+        TJ_STAMP();   // exchange + recurrence done
         it = sh.res_it;
         r_fin = sh.res_rfin;
         const float delta = sh.res_delta;
-        r_mine = (k == 0) ? (float)(0.95 / (1.0 - 0.95)) : sh.nodes[cur ^ 1][k];
-        r_prev = k > 0 ? sh.nodes[cur ^ 1][k - 1] : 0.0f;
-        TJ_STAMP();   // recurrence done
-        cur ^= 1;
-        __syncthreads();          // sh.tot / the other nodes buffer are rewritten next round
-        if (delta <= TJ_ACCEPT || dead) break;
+        if (dbg != nullptr && blockIdx.x == 0 && tid == 0 && round < 24 && round == 0) { dbg[100] = __float_as_uint(sh.res_min); dbg[101] = __float_as_uint(sh.res_rfin); }
+        if (dbg != nullptr && blockIdx.x == 0 && tid == 0 && round < 24)
+            dbg[64 + round] = ((unsigned long long)it << 32) | __float_as_uint(delta);
+        rn_l = lane < K ? sh.nodes[lane] : 1.0f;
+        if (lane == 0) rn_l = (float)(0.95 / (1.0 - 0.95));
+        r_mine = __shfl(rn_l, k, WAVE);
+        r_prev = k > 0 ? __shfl(rn_l, k - 1, WAVE) : 0.0f;
+        if (round == 0) {
+            // the true minimum is known now: residuals.sub_(min) (:27), e = exp(-residuals) (:28)
+            gmin = sh.res_min;
+            cshift = gmin;
+            if (E > 0) {
+#pragma unroll
+                for (int j = 0; j < EE; ++j) {
+                    const float l = e[j] - gmin;
+                    if (j < cnt && k == 0) res[lo + tid + (int64_t)j * TJ_BLOCK] = l;
+                    e[j] = j < cnt ? expf(-l) : 0.0f;
+                }
+                e_ready = true;
+            }
+        }
+        __syncthreads();          // sh.nodes / sh.res_* are rewritten next round
+        if (delta <= TJ_ACCEPT) { accepted = true; break; }
+        if (dead) break;
     }
+    // K+2 rounds always suffice (every round makes one more node exact); anything else is a bug
+    // or a non-finite input: report it instead of returning silently wrong posteriors
+    if (!accepted && tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
 
     // ---- weights = pi / max(pi); max is attained at e = 1 (the min-residual sample) (:38)
     const float tmax = r_fin;
@@ -361,7 +399,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
         } else {
             for (int64_t i = lo + tid; i < hi; i += TJ_BLOCK) {
                 if (pm == k) {
-                    const float l = res[i] - mn;
+                    const float l = res[i] - gmin;
                     const float t = r_fin * expf(-l);
                     res[i] = l;
                     wts[i] = t * __builtin_amdgcn_rcpf(1.0f + t) * inv_pmax;
@@ -373,13 +411,16 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
     }
     TJ_STAMP();   // final stores issued
     if (dbg != nullptr && blockIdx.x == 0 && tid == 0) dbg[63] = (unsigned long long)dbgi;
-    if (blockIdx.x == 0 && tid == 0) {
-        if (out_iters != nullptr) *out_iters = it;
-        state->n = (long long)N;
-        state->k = K;
-        for (int q = 0; q < K; ++q) state->nodes[q] = sh.nodes[cur][q];
-        __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && tid < WAVE) {
+        if (tid == 0) {
+            if (out_iters != nullptr) *out_iters = it;
+            state->n = (long long)N;
+            state->k = K;
+            state->shift = gmin;
+            __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < K) state->nodes[tid] = rn_l;
     }
 }
 
@@ -393,6 +434,7 @@ int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxi
     const int K = maxiter;
     int S = (MAX_COOP_WG - 1) / K;
     if (S < 1) return 0;
+    if (S > TJ_MAXS) S = TJ_MAXS;
     static const int force_s = getenv("RLVI_TJ_S") ? atoi(getenv("RLVI_TJ_S")) : 0;
     if (force_s > 0 && force_s < S) S = force_s;
     const int64_t smax = (N + 4095) / 4096;        // at least 4 samples per thread and slice
@@ -405,8 +447,7 @@ int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxi
     hipLaunchKernelGGL((estep_traj_kernel<E_>), dim3(grid), dim3(TJ_BLOCK), 0, st, res, wts, N,  \
                        tol, K, S, out_iters, trace, ws, mstep_out, mstep_scale, dbg)
     if (L <= (int64_t)TJ_BLOCK * 4) RLVI_TJ(4);
-    else if (L <= (int64_t)TJ_BLOCK * 16) RLVI_TJ(16);
-    else if (L <= (int64_t)TJ_BLOCK * 64) RLVI_TJ(64);
+    else if (L <= (int64_t)TJ_BLOCK * 12) RLVI_TJ(12);
     else RLVI_TJ(0);
 #undef RLVI_TJ
     *rc = (int)hipGetLastError();

@@ -91,8 +91,16 @@ with torch.cuda.stream(side):
         import numpy as np
         from rlvi_amd import _lib
         off = 1024 + 16384 + 32768 + 512 + 32768      # WS_SCRATCH_OFF (rlvi_common.h)
-        raw = ws.buf[off:off + 64 * 8].cpu().numpy().view(np.uint64)
+        raw = ws.buf[off:off + 200 * 8].cpu().numpy().view(np.uint64)
         n = int(raw[63])
         st = raw[:n].astype(np.int64)
-        print("stamps (us since kernel start):", [round(float(x - st[0]) / 100.0, 2) for x in st])
+        print("stamps (us since kernel start):", [round(float(x - st[0]) / 100.0, 2) for x in st][:16])
+        print('finite mask %x scale' % int(raw[102]), np.array([raw[103] & 0xFFFFFFFF], np.uint32).view(np.float32), 'totals lanes0-7 (S,P,D):', raw[104:128].view(np.float64).reshape(8,3))
+        print('round_ok', int(raw[128]), 'it', int(raw[129] >> 32), 'delta', np.array([raw[129] & 0xFFFFFFFF], np.uint32).view(np.float32))
+        nn = raw[130:130+44]
+        print('rn  :', np.array(nn >> 32, np.uint32).view(np.float32)[:44])
+        print('rnew:', np.array(nn & 0xFFFFFFFF, np.uint32).view(np.float32)[:44])
+        rd = raw[64:88]
+        print('min, rfin:', np.array([raw[100] & 0xFFFFFFFF, raw[101] & 0xFFFFFFFF], np.uint32).view(np.float32))
+        print("rounds (it, delta):", [(int(x >> 32), float(np.array([x & 0xFFFFFFFF], np.uint32).view(np.float32)[0])) for x in rd if x][:12])
     print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
