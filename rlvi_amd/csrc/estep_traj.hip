@@ -27,6 +27,8 @@
 
 namespace rlvi {
 
+typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
+
 constexpr int TJ_BLOCK = 1024;
 constexpr int TJ_NW = TJ_BLOCK / WAVE;
 constexpr int TJ_MAXK = 64;
@@ -71,15 +73,19 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
                                          unsigned long long *dbg = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
-    double a = group_allreduce<WAVE>((double)fS, FAdd());
-    double b = group_allreduce<WAVE>((double)fP, FAdd());
-    double c = group_allreduce<WAVE>((double)fD, FAdd());
+    // wave level in fp32 (one fused v_add_f32_dpp per butterfly step; <= 704 terms per wave, error
+    // ~1e-7 relative, below the fp32 rounding of mean(pi) itself), fp64 across waves / workgroups
+    const float a = group_allreduce<WAVE>(fS, FAdd());
+    const float b = group_allreduce<WAVE>(fP, FAdd());
+    const float c = group_allreduce<WAVE>(fD, FAdd());
     float mn = FIRST ? group_allreduce<WAVE>(fmin_, FMin()) : 0.0f;
     if (lane == 0) {
-        sh.part[wave][0] = a; sh.part[wave][1] = b; sh.part[wave][2] = c;
+        sh.part[wave][0] = (double)a; sh.part[wave][1] = (double)b; sh.part[wave][2] = (double)c;
         if (FIRST) sh.pmin[wave] = mn;
     }
     __syncthreads();
+#define TJ_RS(i) do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && xstep < 4) dbg[200 + xstep * 8 + (i)] = wall_clock64(); } while (0)
+    TJ_RS(0);
     constexpr int NQ = FIRST ? 8 : 6;
     constexpr int PER = MAX_COOP_WG / WAVE;          // polling waves (one record per lane each)
     auto dbl = [](unsigned long long lo, unsigned long long hi) {
@@ -104,6 +110,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    TJ_RS(1);
     // waves 0..3 sweep 64 records each (one record per lane, all its granules in flight) into LDS
     if (wave < PER && !dead) {
         const int w = wave * WAVE + lane;
@@ -111,13 +118,27 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
         gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG2_GRANULES;
         const unsigned long long t0 = wall_clock64();
         bool timeout = false;
-        unsigned long long x[NQ];
+        unsigned long long x[8];
         for (unsigned spin = 0;; ++spin) {
             bool ok = true;
             if (mine) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    x[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the 64-byte record as four 16-byte agent-scope (sc1) loads in flight together:
+                // half the requests of 8-byte loads; each 8-byte granule is self-tagged, so it does
+                // not matter that a 16-byte load is only granule-atomic
+                vu4 q0, q1, q2, q3;
+                asm volatile(
+                    "global_load_dwordx4 %0, %4, off sc1\n\t"
+                    "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                    "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                    "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                    : "v"((unsigned long long)(uintptr_t)p)
+                    : "memory");
+                x[0] = ((unsigned long long)q0.y << 32) | q0.x; x[1] = ((unsigned long long)q0.w << 32) | q0.z;
+                x[2] = ((unsigned long long)q1.y << 32) | q1.x; x[3] = ((unsigned long long)q1.w << 32) | q1.z;
+                x[4] = ((unsigned long long)q2.y << 32) | q2.x; x[5] = ((unsigned long long)q2.w << 32) | q2.z;
+                x[6] = ((unsigned long long)q3.y << 32) | q3.x; x[7] = ((unsigned long long)q3.w << 32) | q3.z;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) ok = ok && (uint32_t)(x[q] >> 32) == tag;
             }
@@ -134,7 +155,9 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             for (int q = 0; q < NQ / 2; ++q) sh.rec[w][q] = dbl(x[2 * q], x[2 * q + 1]);
         }
     }
+    TJ_RS(2);
     __syncthreads();
+    TJ_RS(3);
     dead = dead || sh.dead != 0;
     if (wave == 0) {
         double tS = 0.0, tP = 0.0, tD = 0.0;
@@ -148,6 +171,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
                 if constexpr (FIRST) gmin = fminf(gmin, (float)sh.rec[w][3]);
             }
         }
+        TJ_RS(4);
         const bool has = lane < K;
         float scale = 1.0f;
         if (FIRST) {
@@ -177,10 +201,28 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
         float rnew_l = rn;
         float avg_l = 0.0f;
         // serial chain; `step` is wave-uniform, so the per-node values come through v_readlane
-        // (SGPR lane select, no LDS):  avg = a0 + b (r - r'),  r <- avg / (1 - avg)
+        // (SGPR lane select, no LDS):  avg = a0 + b (r - r'),  r <- avg / (1 - avg).
+        // Fast form first (five dependent fp32 operations per step); its steps are then checked
+        // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
+        // that left it (cold or poor guesses) is redone in the damped form.
+        {
 #pragma unroll 1
-        for (int step = 0; step < steps; ++step) {
-            {
+            for (int step = 0; step < steps; ++step) {
+                const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
+                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
+                const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
+                if (lane == step) rnew_l = r;
+                const float avg = fmaf(bb, r - rns, a0);
+                if (lane == step) avg_l = avg;
+                r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
+            }
+        }
+        const bool inside = !(has && lane < steps) ||
+                            (fabsf(rnew_l - rn) <= 0.5f * rn && avg_l > 0.0f && avg_l < 0.999999f);
+        if (!__all(inside)) {
+            r = (float)(0.95 / (1.0 - 0.95));
+#pragma unroll 1
+            for (int step = 0; step < steps; ++step) {
                 const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
                 const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
                 const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
@@ -194,6 +236,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
                 r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-37f);              // (:31)
             }
         }
+        TJ_RS(5);
         // nodes beyond the lookahead: a fresh geometric tail from the last corrected node
         {
             const float last = __shfl(rnew_l, steps - 1, WAVE);      // all lanes take part
@@ -227,6 +270,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             trace[2 * lane] = err_l;
             trace[2 * lane + 1] = avg_l;
         }
+        TJ_RS(6);
         const float rfin_w = __shfl(rnew_l, it_now - 1, WAVE);   // all lanes take part
         if (lane == 0) {
             sh.res_it = it_now;
@@ -342,7 +386,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
                            shift, invN, tol, trace, true, dbg);
         else
             tj_round<false>(sh, fS, fP, fD, 0.0f, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
-                            shift, invN, tol, trace, true);
+                            shift, invN, tol, trace, true, dbg);
         ++tag; ++xstep;
         TJ_STAMP();   // exchange + recurrence done
         it = sh.res_it;

@@ -91,7 +91,7 @@ with torch.cuda.stream(side):
         import numpy as np
         from rlvi_amd import _lib
         off = 1024 + 16384 + 32768 + 512 + 32768      # WS_SCRATCH_OFF (rlvi_common.h)
-        raw = ws.buf[off:off + 200 * 8].cpu().numpy().view(np.uint64)
+        raw = ws.buf[off:off + 240 * 8].cpu().numpy().view(np.uint64)
         n = int(raw[63])
         st = raw[:n].astype(np.int64)
         print("stamps (us since kernel start):", [round(float(x - st[0]) / 100.0, 2) for x in st][:16])
@@ -100,6 +100,9 @@ with torch.cuda.stream(side):
         nn = raw[130:130+44]
         print('rn  :', np.array(nn >> 32, np.uint32).view(np.float32)[:44])
         print('rnew:', np.array(nn & 0xFFFFFFFF, np.uint32).view(np.float32)[:44])
+        for xs in range(3):
+            rs = raw[200 + xs * 8: 200 + xs * 8 + 7].astype(np.int64)
+            print('  exchange', xs, '[stage1->, publish, polled, barrier, totals, chain, epilogue] us since kernel start:', [round(float(v - st[0]) / 100.0, 2) for v in rs])
         rd = raw[64:88]
         print('min, rfin:', np.array([raw[100] & 0xFFFFFFFF, raw[101] & 0xFFFFFFFF], np.uint32).view(np.float32))
         print("rounds (it, delta):", [(int(x >> 32), float(np.array([x & 0xFFFFFFFF], np.uint32).view(np.float32)[0])) for x in rd if x][:12])
