@@ -1,5 +1,4 @@
 #!/bin/bash
-for s in 6 3 2 1; do
-RLVI_TJ_S=$s python tools/time_parts.py --what step --tag "step S=$s" 2>/dev/null | tail -1
-RLVI_TJ_S=$s python tools/time_parts.py --what estep --tag "estep(1 round) S=$s" 2>/dev/null | tail -1
+for nb in 256 342 384 512 600 683 768 820; do
+RLVI_MSTEP_BLOCKS=$nb python tools/time_parts.py --what mstep --tag "tile prefetch blocks=$nb" 2>/dev/null | tail -1
 done
