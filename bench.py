@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)")
     ap.add_argument("--profile-only", action="store_true",
                     help="warmup + timed steps only (for rocprofv3 runs)")
     return ap.parse_args()
@@ -86,9 +89,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.same_device:
+        local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
     if a.gpus != world and rank == 0:
@@ -181,7 +189,7 @@ def main():
             ms = e0.elapsed_time(e1)
         sync_all()
         if world > 1:
-            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([ms], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t.item())
         return ms

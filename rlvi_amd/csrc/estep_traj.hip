@@ -182,7 +182,8 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             scale = expf(shift - gmin);
         }
         const float rn = rn_l * scale;
-        bool finite = has ? (tS == tS && tP == tP && tD == tD && tS < 1e300 && tD < 1e300 && tS > 0.0)
+        // (a node far below the trajectory may legitimately have S = 0 after fp32 underflow)
+        bool finite = has ? (tS == tS && tP == tP && tD == tD && tS < 1e300 && tP < 1e300 && tD < 1e300)
                           : true;
         const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
         if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
@@ -233,7 +234,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
                 const float d = fmaxf(fminf(r - rns, h), -h);
                 const float avg = fminf(fmaf(bb, d, a0), 0.999999f);
                 if (lane == step) avg_l = avg;
-                r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-37f);              // (:31)
+                r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-30f);              // (:31)
             }
         }
         TJ_RS(5);
@@ -264,7 +265,10 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             dbg[130 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
             if (lane == 0) { dbg[128] = round_ok; dbg[129] = ((unsigned long long)it_now << 32) | __float_as_uint(delta_w); }
         }
-        if (!round_ok) { delta_w = __builtin_inff(); rnew_l = rn_l; }   // keep the old guesses
+        // guesses stay where sums in fp32 cannot underflow; an invalid round restarts from the
+        // geometric cold guess instead of re-evaluating the nodes that broke it
+        rnew_l = fminf(fmaxf(rnew_l, 1e-30f), 1e30f);
+        if (!round_ok) { delta_w = __builtin_inff(); rnew_l = 19.0f * exp2f(-(float)lane); }
         if (has && want_nodes) sh.nodes[lane] = rnew_l;
         if (trace != nullptr && blockIdx.x == 0 && lane < it_now && round_ok) {
             trace[2 * lane] = err_l;

@@ -51,6 +51,12 @@ def exchange_residuals_owned(residuals, start, stop, group=None):
     n = stop - start
     if residuals.shape[0] != n * world:
         raise ValueError("owned exchange needs equal contiguous slices covering the vector")
+    if residuals.is_cuda and dist.get_backend(group) == "gloo":
+        # debugging on a box without RCCL peers (e.g. several ranks sharing one GPU): stage on host
+        host = torch.empty(residuals.shape, dtype=residuals.dtype)
+        dist.all_gather_into_tensor(host, residuals[start:stop].cpu(), group=group)
+        residuals.copy_(host)
+        return
     dist.all_gather_into_tensor(residuals, residuals[start:stop].clone(), group=group)
 
 

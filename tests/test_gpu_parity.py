@@ -492,3 +492,26 @@ def test_weighted_ce_autograd(gpu, oracle):
     ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], d["residuals"].copy())
     assert abs(float(loss) - float(ref["loss"])) <= REL * abs(float(ref["loss"]))
     np.testing.assert_allclose(z.grad.cpu().numpy(), 2.0 * ref["grad"], rtol=1e-4, atol=2e-6)
+
+
+def test_epoch_driver_end_to_end(gpu, tmp_path):
+    """main.py:run()-equivalent for RLVI on MNIST-shaped synthetic data with 50 %
+    symmetric label noise.  RLVI has to do its job: the posteriors separate clean from corrupted
+    samples and the clean-label test accuracy ends far above the 50 % agreement with the noisy
+    labels it is trained on; the TSV log keeps main.py's columns (:184-193,:347-350)."""
+    torch, ops, dev = gpu
+    from rlvi_amd import driver
+    log = tmp_path / "rlvi.tsv"
+    logs, weights, clean = driver.run(n_train=8192, n_val=1024, n_test=2048, batch_size=1024,
+                                      n_epoch=9, noise_rate=0.5, lr=0.1, log_path=str(log),
+                                      device="cuda:0", return_state=True)
+    last = logs[-1]
+    assert last["test_acc"] > 95.0, last
+    assert last["train_acc"] < 75.0            # agreement with the NOISY labels stays near 50 %
+    w = weights.cpu().numpy()
+    assert (w[clean] > 0.5).mean() > 0.9 and (w[~clean] > 0.5).mean() < 0.05
+    lines = log.read_text().strip().splitlines()
+    assert lines[0].split("\t") == ["epoch:", "time_ep", "tau", "fix", "clean,%", "corr,%",
+                                     "train_acc", "val_acc", "test_acc"]
+    assert len(lines) == 1 + len(logs)
+    assert ops.workspace(dev).status() == 0
