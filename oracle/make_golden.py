@@ -15,6 +15,7 @@ Golden sets:
   G4 epoch        whole train_rlvi epochs          train_rlvi.py:52-106
   G5 standard     update_weights, linear/logistic  standard-learning/rlvi.py
   G6 online       update_weights_rlvi, CE          online-learning/main.py:45-58,:84-85
+  G7 estimators   mean, pca, covariance            standard-learning/rlvi.py:23-65,:111-144
 """
 import argparse
 import os
@@ -337,7 +338,26 @@ def gen_g6(ref):
     save("g6_online", **out)
 
 
-GROUPS = {"g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
+def gen_g7(ref):
+    """standard-learning estimators on top of the same E-step: mean, pca, covariance
+    (rlvi.py:46-65, :111-144) and update_weights_constrained (:23-43)."""
+    sys.path.insert(0, os.path.join(ref, "standard-learning"))
+    import rlvi as ref_rlvi
+    out = {}
+    for size, seed in ((60, 2), (200, 1)):
+        x = synth.heavy_tail_cloud(size=size, eps=0.2, seed=seed)
+        out[f"mean_{size}/theta"] = ref_rlvi.mean(x.copy())
+        out[f"pca_{size}/theta"] = ref_rlvi.pca(x.copy())
+        out[f"cov_{size}/theta"] = ref_rlvi.covariance(x.copy(), eps=0.4)
+        out[f"seed_{size}"] = np.array(seed)
+    l = synth.residual_vector("heavy", 100, seed=5).astype(np.float64)
+    out["uwc/losses"] = l
+    out["uwc/n_eff"] = np.array(60.0)
+    out["uwc/w"] = ref_rlvi.update_weights_constrained(l.copy(), 60.0)
+    save("g7_estimators", **out)
+
+
+GROUPS = {"g7": gen_g7, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -251,3 +251,98 @@ def linear_regression(X, y, maxiter=100, tol=1e-3, trace=False):
     if trace:
         return theta, w, outer
     return theta
+
+
+# ---- estimators of SURVEY 8(f)-2, restated around the same E-step -------------------------
+def update_weights_constrained(losses, n_eff, tol=1e-3, maxiter=100):
+    """rlvi.py:23-43: unconstrained E-step, then the KKT shift if sum(w) < n_eff
+    (the 1-D solve is scipy's minimize_scalar, as in the reference)."""
+    from scipy import optimize as opt
+    losses = np.asarray(losses, np.float64)
+    n = len(losses)
+    w = update_weights(losses, tol=tol, maxiter=maxiter)
+
+    def shift_obj(s):
+        return np.square(np.sum(np.exp(-losses + s) / ((n - n_eff) / n_eff + np.exp(-losses + s))) - n_eff)
+    if np.sum(w) < n_eff:
+        shift = opt.minimize_scalar(shift_obj)['x']
+        w = np.exp(-losses + shift) / ((n - n_eff) / n_eff + np.exp(-losses + shift))
+    return w
+
+
+def _gauss_losses(sample, theta, w):
+    r = np.linalg.norm(theta - sample, axis=1) ** 2
+    return 0.5 * r / (w @ r / np.sum(w))
+
+
+def mean(sample, maxiter=100, tol=1e-3):
+    """rlvi.py:46-65."""
+    sample = np.asarray(sample, np.float64)
+    w = np.ones(sample.shape[0])
+    theta = w @ sample / np.sum(w)
+    losses = _gauss_losses(sample, theta, w)
+    for _ in range(maxiter):
+        w = update_weights(losses)
+        prev = theta.copy()
+        theta = w @ sample / np.sum(w)
+        losses = _gauss_losses(sample, theta, w)
+        if np.linalg.norm(theta - prev) / np.linalg.norm(prev) <= tol:
+            break
+    return theta
+
+
+def _pca_step(sample, w):
+    """utils.pca (standard-learning/utils.py:76-89): first principal axis of diag(w) @ samples
+    (sklearn PCA centres the weighted rows), loss = |x|^2 - (x.theta)^2."""
+    z = w[:, None] * sample
+    z = z - z.mean(0)
+    _, _, vt = np.linalg.svd(z, full_matrices=False)
+    theta = vt[0] / np.linalg.norm(vt[0])
+    # sklearn's svd_flip(u_based_decision=False): the largest-magnitude entry of the axis is > 0
+    if theta[np.argmax(np.abs(theta))] < 0:
+        theta = -theta
+    losses = np.sum(sample ** 2, axis=1) - (sample @ theta) ** 2
+    return theta, losses
+
+
+def pca(sample, maxiter=100, tol=1e-2):
+    """rlvi.py:111-125 (theta_init=None)."""
+    sample = np.asarray(sample, np.float64)
+    w = np.ones(sample.shape[0])
+    theta, losses = _pca_step(sample, w)
+    for _ in range(maxiter):
+        w = update_weights(losses)
+        prev = theta.copy()
+        theta, losses = _pca_step(sample, w)
+        if np.linalg.norm(theta - prev) / np.linalg.norm(prev) <= tol:
+            break
+    return theta
+
+
+def _cov_step(sample, w):
+    """utils.covariance (utils.py:92-108): weighted mean / covariance, Gaussian NLL per sample."""
+    mu = sample.T @ w / np.sum(w)
+    c = sample - mu
+    cov = c.T @ (w[:, None] * c) / np.sum(w)
+    sol = np.linalg.solve(cov, c.T)
+    r = np.sum(c * sol.T, axis=1)
+    sign, logdet = np.linalg.slogdet(cov)
+    if sign <= 0:
+        raise ValueError("Singular covariance matrix")
+    return cov, 0.5 * (r + logdet + mu.shape[0] * np.log(2 * np.pi))
+
+
+def covariance(sample, eps, maxiter=100, tol=1e-2):
+    """rlvi.py:128-144."""
+    sample = np.asarray(sample, np.float64)
+    n = sample.shape[0]
+    n_eff = n * (1 - eps)
+    w = np.ones(n)
+    theta, losses = _cov_step(sample, w)
+    for _ in range(maxiter):
+        w = update_weights_constrained(losses, n_eff)
+        prev = theta.copy()
+        theta, losses = _cov_step(sample, w)
+        if np.linalg.norm(theta - prev, ord='fro') / np.linalg.norm(prev, ord='fro') <= tol:
+            break
+    return theta

@@ -1,6 +1,8 @@
 """MI355X mirror of standard-learning/rlvi.py (numpy in, numpy out, fp64).
 
     update_weights(losses, tol=1e-3, maxiter=100)             reference rlvi.py:8-20
+    update_weights_constrained(losses, n_eff, ...)            reference rlvi.py:23-43
+    mean / pca / covariance                                    reference rlvi.py:46-65, :111-144
     linear_regression(X, y, maxiter=100, tol=1e-3) -> theta    reference rlvi.py:68-89
     logistic_regression(X, y, maxiter=100, tol=1e-2) -> theta  reference rlvi.py:92-108
 
@@ -85,5 +87,99 @@ def logistic_regression(X, y, maxiter=100, tol=1e-2):
         prev = theta.copy()
         theta, losses = _sklearn_log_reg(Xh, yh, Xd, w)
         if np.linalg.norm(theta - prev) / np.linalg.norm(prev) <= tol:
+            break
+    return theta
+
+
+# ---- the remaining estimators of standard-learning/rlvi.py on the same GPU E-step.
+# n is tens to hundreds here: the E-step runs in librlvi_gfx950.so, the small dense algebra around
+# it (weighted means, a 2x2 SVD / solve, scipy's 1-D KKT solve) stays on the host as numpy, exactly
+# where the reference has it.
+def update_weights_constrained(losses, n_eff, tol=1e-3, maxiter=100):
+    """rlvi.py:23-43."""
+    from scipy import optimize as opt
+    losses = np.asarray(losses, np.float64)
+    n = len(losses)
+    w = update_weights(losses, tol=tol, maxiter=maxiter)
+
+    def shift_obj(s):
+        return np.square(np.sum(np.exp(-losses + s) / ((n - n_eff) / n_eff + np.exp(-losses + s))) - n_eff)
+    if np.sum(w) < n_eff:
+        shift = opt.minimize_scalar(shift_obj)['x']
+        w = np.exp(-losses + shift) / ((n - n_eff) / n_eff + np.exp(-losses + shift))
+    return w
+
+
+def _gauss_losses(sample, theta, w):
+    r = np.linalg.norm(theta - sample, axis=1) ** 2
+    return 0.5 * r / (w @ r / np.sum(w))
+
+
+def mean(sample, maxiter=100, tol=1e-3):
+    """rlvi.py:46-65."""
+    sample = np.asarray(sample, np.float64)
+    w = np.ones(sample.shape[0])
+    theta = w @ sample / np.sum(w)
+    losses = _gauss_losses(sample, theta, w)
+    for _ in range(maxiter):
+        w = update_weights(losses)
+        prev = theta.copy()
+        theta = w @ sample / np.sum(w)
+        losses = _gauss_losses(sample, theta, w)
+        if np.linalg.norm(theta - prev) / np.linalg.norm(prev) <= tol:
+            break
+    return theta
+
+
+def _pca_step(sample, w):
+    """utils.pca (standard-learning/utils.py:76-89) with the PCA fit as an SVD of the centred,
+    weight-scaled rows and sklearn's sign convention."""
+    z = w[:, None] * sample
+    z = z - z.mean(0)
+    _, _, vt = np.linalg.svd(z, full_matrices=False)
+    theta = vt[0] / np.linalg.norm(vt[0])
+    if theta[np.argmax(np.abs(theta))] < 0:      # sklearn's svd_flip(u_based_decision=False)
+        theta = -theta
+    return theta, np.sum(sample ** 2, axis=1) - (sample @ theta) ** 2
+
+
+def pca(sample, maxiter=100, tol=1e-2):
+    """rlvi.py:111-125 (theta_init=None)."""
+    sample = np.asarray(sample, np.float64)
+    w = np.ones(sample.shape[0])
+    theta, losses = _pca_step(sample, w)
+    for _ in range(maxiter):
+        w = update_weights(losses)
+        prev = theta.copy()
+        theta, losses = _pca_step(sample, w)
+        if np.linalg.norm(theta - prev) / np.linalg.norm(prev) <= tol:
+            break
+    return theta
+
+
+def _cov_step(sample, w):
+    """utils.covariance (utils.py:92-108)."""
+    mu = sample.T @ w / np.sum(w)
+    c = sample - mu
+    cov = c.T @ (w[:, None] * c) / np.sum(w)
+    r = np.sum(c * np.linalg.solve(cov, c.T).T, axis=1)
+    sign, logdet = np.linalg.slogdet(cov)
+    if sign <= 0:
+        raise ValueError("Singular covariance matrix")
+    return cov, 0.5 * (r + logdet + mu.shape[0] * np.log(2 * np.pi))
+
+
+def covariance(sample, eps, maxiter=100, tol=1e-2):
+    """rlvi.py:128-144."""
+    sample = np.asarray(sample, np.float64)
+    n = sample.shape[0]
+    n_eff = n * (1 - eps)
+    w = np.ones(n)
+    theta, losses = _cov_step(sample, w)
+    for _ in range(maxiter):
+        w = update_weights_constrained(losses, n_eff)
+        prev = theta.copy()
+        theta, losses = _cov_step(sample, w)
+        if np.linalg.norm(theta - prev, ord='fro') / np.linalg.norm(prev, ord='fro') <= tol:
             break
     return theta

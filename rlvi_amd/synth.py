@@ -76,3 +76,17 @@ def logistic_data(B=256, d=60, seed=0):
     w = rng.standard_normal(d) / np.sqrt(d)
     b = 0.1
     return X, w, b
+
+
+def heavy_tail_cloud(size=200, eps=0.2, nu=1.5, seed=0, corr=0.8):
+    """2-D sample for the mean / pca / covariance estimators: a correlated Gaussian cloud with an
+    eps-fraction of multivariate-t outliers (the recipe of standard-learning/main.py:44-67,
+    :124-167 with a fixed seed)."""
+    rng = np.random.default_rng(seed)
+    n2 = rng.binomial(n=size, p=eps)
+    n1 = size - n2
+    root = np.linalg.cholesky(np.array([[1.0, corr], [corr, 1.0]]))
+    s1 = root @ rng.normal(size=(2, n1))
+    u = rng.chisquare(df=nu, size=n2) / nu
+    s2 = (root @ rng.normal(size=(2, n2))) / np.sqrt(u[None, :])
+    return np.hstack([s1, s2]).T

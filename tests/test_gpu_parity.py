@@ -446,6 +446,19 @@ def test_standard_and_online_mirrors_golden(golden, gpu, oracle):
                                oracle.update_weights_rlvi(oracle.logistic_nll(Xl, wl, b)), rtol=1e-10)
 
 
+def test_estimators_mean_pca_covariance_golden(golden, gpu):
+    """the remaining standard-learning estimators on the GPU E-step."""
+    from rlvi_amd import standard
+    g = golden("g7_estimators")
+    for size in (60, 200):
+        x = synth.heavy_tail_cloud(size=size, eps=0.2, seed=int(g[f"seed_{size}"]))
+        np.testing.assert_allclose(standard.mean(x), g[f"mean_{size}/theta"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(standard.pca(x), g[f"pca_{size}/theta"], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(standard.covariance(x, eps=0.4), g[f"cov_{size}/theta"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(standard.update_weights_constrained(g["uwc/losses"], float(g["uwc/n_eff"])),
+                               g["uwc/w"], rtol=1e-6, atol=1e-300)
+
+
 # ------------------------------------------------------------------------------ whole epochs
 def test_train_rlvi_epochs_golden(golden, gpu):
     """G4: the drop-in train_rlvi on the GPU against four reference epochs (overfit F,F,T,T)."""
