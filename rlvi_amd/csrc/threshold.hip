@@ -91,7 +91,9 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
                                                               float alpha,
                                                               float *__restrict__ thr_io,
                                                               uint8_t *__restrict__ mask,
-                                                              int64_t *__restrict__ kept_out) {
+                                                              int64_t *__restrict__ kept_out,
+                                                              const int32_t *__restrict__ only_if) {
+    if (only_if != nullptr && *only_if == 0) return;     // the fast form already did the work
     Keys<E> keys;
     keys.load(w, N);
 
@@ -185,6 +187,142 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fast form for weights in [0, 1] (what the E-step produces): (1 - pi) * 2^24 is an exact
+// integer <= 2^24, so the prefix sums are plain integer sums (u32 per thread, u64 across the
+// workgroup) -- six 32-bit VALU operations per key and bisection round instead of fp64 adds.
+// The first pass checks the range; outside [0, 1] the generic kernel above is used instead
+// (signalled through *fallback).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, int tag) {
+    __shared__ unsigned long long sh[2][THR_NW];
+    __shared__ unsigned long long out[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) sh[tag & 1][wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long t = lane < THR_NW ? sh[tag & 1][lane] : 0ull;
+        t = wave_sum(t);
+        if (lane == 0) out[tag & 1] = t;
+    }
+    __syncthreads();
+    return out[tag & 1];      // double-buffered by `tag`: the next call may start before all read
+}
+
+__device__ __forceinline__ uint32_t one_minus_u(float p) {
+    return (uint32_t)__float2uint_rn((1.0f - p) * 16777216.0f);
+}
+
+template <int E, bool TRUNC>
+__global__ __launch_bounds__(THR_BLOCK) void threshold_fast_kernel(float *__restrict__ w, int64_t N,
+                                                                   float alpha,
+                                                                   float *__restrict__ thr_io,
+                                                                   uint8_t *__restrict__ mask,
+                                                                   int64_t *__restrict__ kept_out,
+                                                                   int32_t *__restrict__ fallback) {
+    float p[E];
+    int cnt = 0;
+    unsigned long long tot = 0ull;
+    float pmin = __builtin_inff(), pmax = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = (int64_t)j * THR_BLOCK + threadIdx.x;
+        if (i < N) {
+            p[j] = w[i];
+            cnt = j + 1;
+            pmin = fminf(pmin, p[j]);
+            pmax = fmaxf(pmax, p[j]);
+            tot += one_minus_u(p[j]);
+        } else {
+            p[j] = -1.0f;          // never >= a candidate in [0, 1]
+        }
+    }
+    Red3 r = block_reduce3((double)0.0, (unsigned long long)f32_key(pmin), (unsigned long long)f32_key(pmax));
+    const float gmin = key_f32((uint32_t)r.a), gmax = key_f32((uint32_t)r.b);
+    if (!(gmin >= 0.0f && gmax <= 1.0f) || (__float_as_uint(gmin) >> 31)) {   // NaN, -0.0 too
+        if (threadIdx.x == 0) *fallback = 1;
+        return;
+    }
+    int tag = 0;
+    const unsigned long long total = block_sum_u64(tot, tag++);
+    const float beta = (float)((double)total * (1.0 / 16777216.0)) * alpha;     // (:43-44)
+    auto pred = [&](unsigned long long s_int) {       // fl32(prefix) <= beta   (:46-47)
+        return (float)((double)s_int * (1.0 / 16777216.0)) <= beta;
+    };
+
+    // smallest candidate value c (as an fp32 bit pattern; weights >= 0 so bits are ordered) in
+    // [gmin, next(gmax)] with  sum_{pi >= c} (1 - pi)  <= beta
+    unsigned long long lo = __float_as_uint(gmin), hi = (unsigned long long)__float_as_uint(gmax) + 1ull;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        const float c = __uint_as_float((uint32_t)mid);
+        uint32_t s = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) s += (p[j] >= c) ? one_minus_u(p[j]) : 0u;
+        if (pred(block_sum_u64((unsigned long long)s, tag++))) hi = mid; else lo = mid + 1ull;
+    }
+    // c* = lo.  lo == bits(gmax)+1 means even the top group alone does not fit.
+    const bool top_empty = lo > (unsigned long long)__float_as_uint(gmax);
+    const float cstar = top_empty ? __builtin_inff() : __uint_as_float((uint32_t)lo);
+    uint32_t s_in = 0, n_in = 0;
+    float below = -1.0f, above = __builtin_inff();       // max{pi < c*}, min{pi >= c*}
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (j < cnt) {
+            if (p[j] >= cstar) { s_in += one_minus_u(p[j]); ++n_in; above = fminf(above, p[j]); }
+            else below = fmaxf(below, p[j]);
+        }
+    }
+    const unsigned long long S = block_sum_u64((unsigned long long)s_in, tag++);
+    const unsigned long long cnt_in = block_sum_u64((unsigned long long)n_in, tag++);
+    r = block_reduce3(0.0, (unsigned long long)f32_key(above), (unsigned long long)f32_key(below));
+    above = key_f32((uint32_t)r.a);
+    below = key_f32((uint32_t)r.b);
+
+    float thr;
+    if (below < 0.0f) {
+        thr = gmin;                                   // every element inside: count = N
+    } else {
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) m += (j < cnt && p[j] == below) ? 1u : 0u;
+        const unsigned long long mult = block_sum_u64((unsigned long long)m, tag++);
+        const unsigned long long t = one_minus_u(below);
+        long long jl = 0, jh = (long long)mult;       // pred(jl) true, pred(jh) false
+        while (jh - jl > 1) {
+            const long long jm = jl + ((jh - jl) >> 1);
+            if (pred(S + (unsigned long long)jm * t)) jl = jm; else jh = jm;
+        }
+        const long long j = pred(S) ? jl : 0;         // S = 0 (empty top) always fits: beta >= 0
+        if (cnt_in + (unsigned long long)j == 0ull) thr = gmin;     // last_index = -1 wraps (:47-48)
+        else if (j >= 1) thr = below;
+        else thr = above;
+    }
+    if (TRUNC) {
+        const float prev = *thr_io;
+        if (!(thr > prev)) thr = prev;                // threshold = max(threshold, criterion) (:102)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *thr_io = thr;
+    if (TRUNC) {
+        uint32_t kept = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int64_t i = (int64_t)j * THR_BLOCK + threadIdx.x;
+            if (j < cnt) {
+                float x = p[j];
+                if (x < thr) { x = 0.0f; w[i] = 0.0f; }      // :103
+                const bool mk = x > thr;                     // main.py:343
+                if (mask != nullptr) mask[i] = mk ? 1 : 0;
+                kept += mk ? 1u : 0u;
+            }
+        }
+        const unsigned long long k = block_sum_u64((unsigned long long)kept, tag++);
+        if (threadIdx.x == 0 && kept_out != nullptr) *kept_out = (int64_t)k;
+    }
+}
+
 __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, int64_t N,
                                                        const float *__restrict__ thr_p,
                                                        uint8_t *__restrict__ mask) {
@@ -196,18 +334,30 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
     }
 }
 
+// Single workgroup.  N <= 65536: the integer fast form with the weights in registers (16 or 64
+// per thread); it hands over to the generic fp64 form (streaming, any N, any range) by setting a
+// flag the generic kernel reads at its start -- both are enqueued, the second is a no-op when the
+// first one succeeded.
+__global__ void threshold_flag_clear(int32_t *flag) { *flag = 0; }
+
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
-                            int64_t *kept, hipStream_t st) {
-    if (N <= (int64_t)THR_BLOCK * 16)
-        hipLaunchKernelGGL((threshold_kernel<16, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N,
-                           alpha, thr, mask, kept);
-    else if (N <= (int64_t)THR_BLOCK * 80)
-        hipLaunchKernelGGL((threshold_kernel<80, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N,
-                           alpha, thr, mask, kept);
-    else
-        hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N,
-                           alpha, thr, mask, kept);
+                            int64_t *kept, void *ws, hipStream_t st) {
+    int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
+    if (N <= (int64_t)THR_BLOCK * 64) {
+        hipLaunchKernelGGL(threshold_flag_clear, dim3(1), dim3(1), 0, st, flag);
+        if (N <= (int64_t)THR_BLOCK * 16)
+            hipLaunchKernelGGL((threshold_fast_kernel<16, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w,
+                               N, alpha, thr, mask, kept, flag);
+        else
+            hipLaunchKernelGGL((threshold_fast_kernel<64, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w,
+                               N, alpha, thr, mask, kept, flag);
+        hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha,
+                           thr, mask, kept, flag);
+    } else {
+        hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha,
+                           thr, mask, kept, (const int32_t *)nullptr);
+    }
     return (int)hipGetLastError();
 }
 
@@ -217,25 +367,23 @@ using namespace rlvi;
 
 extern "C" int rlvi_fn_threshold_f32(const float *weights, int64_t N, float alpha, float *thr_out,
                                      void *ws, void *stream) {
-    (void)ws;
-    if (!weights || !thr_out) return RLVI_E_NULL;
+    if (!weights || !thr_out || !ws) return RLVI_E_NULL;
     if (N <= 0) return RLVI_E_SHAPE;
     if (N > (1ll << 29)) return RLVI_E_LIMIT;   // exactness bound of the fp64 prefix sums
     if (((uintptr_t)weights & 3) || ((uintptr_t)thr_out & 3)) return RLVI_E_ALIGN;
     return launch_threshold<false>(const_cast<float *>(weights), N, alpha, thr_out, nullptr,
-                                   nullptr, static_cast<hipStream_t>(stream));
+                                   nullptr, ws, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rlvi_threshold_truncate_f32(float *weights, int64_t N, float alpha,
                                            float *thr_inout, uint8_t *mask_gt, int64_t *kept_out,
                                            void *ws, void *stream) {
-    (void)ws;
-    if (!weights || !thr_inout) return RLVI_E_NULL;
+    if (!weights || !thr_inout || !ws) return RLVI_E_NULL;
     if (N <= 0) return RLVI_E_SHAPE;
     if (N > (1ll << 29)) return RLVI_E_LIMIT;
     if (((uintptr_t)weights & 3) || ((uintptr_t)thr_inout & 3) || ((uintptr_t)kept_out & 7))
         return RLVI_E_ALIGN;
-    return launch_threshold<true>(weights, N, alpha, thr_inout, mask_gt, kept_out,
+    return launch_threshold<true>(weights, N, alpha, thr_inout, mask_gt, kept_out, ws,
                                   static_cast<hipStream_t>(stream));
 }
 

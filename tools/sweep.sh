@@ -1,4 +1,3 @@
 #!/bin/bash
-for nb in 256 342 384 512 600 683 768 820; do
-RLVI_MSTEP_BLOCKS=$nb python tools/time_parts.py --what mstep --tag "tile prefetch blocks=$nb" 2>/dev/null | tail -1
-done
+python tools/time_parts.py --what thr --tag "threshold+truncate N=65536" 2>&1 | tail -1
+python tools/time_parts.py --what thr --n 8192 --tag "threshold+truncate N=8192" 2>&1 | tail -1

@@ -61,7 +61,10 @@ with torch.cuda.stream(side):
             residuals.copy_(res_src)
             ops.estep_deep(residuals, weights, iters=iters, ws=ws)
         elif a.what == "thr":
-            ops.threshold_truncate(weights, 0.0, ws=ws)
+            from rlvi_amd import _lib
+            L = _lib.load()
+            _lib.check(L.rlvi_threshold_truncate_f32(ops._ptr(weights), weights.shape[0], 0.05, ops._ptr(thr),
+                                                     None, None, ws.ptr, ops._stream_ptr()), "thr")
         elif a.what == "fused":
             ops.fused_em(logits[r], labels, pi, ws=ws, out=out, grad=grads[r], rows=rows, iters=iters)
     for i in range(12):
