@@ -92,7 +92,7 @@ struct VecIO<uint16_t, 8> : VecIOBase<uint16_t, 8, VecIO<uint16_t, 8>> {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+            w[i] = f32x2_to_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -105,8 +105,8 @@ struct VecIO<uint16_t, 4> : VecIOBase<uint16_t, 4, VecIO<uint16_t, 4>> {
     }
     static __device__ __forceinline__ void store(uint16_t *p, const float (&v)[4]) {
         uint2 t;
-        t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        t.x = f32x2_to_bf16x2(v[0], v[1]);
+        t.y = f32x2_to_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2 *>(p) = t;
     }
 };
@@ -117,8 +117,7 @@ struct VecIO<uint16_t, 2> : VecIOBase<uint16_t, 2, VecIO<uint16_t, 2>> {
         v[0] = __uint_as_float(t << 16); v[1] = __uint_as_float(t & 0xFFFF0000u);
     }
     static __device__ __forceinline__ void store(uint16_t *p, const float (&v)[2]) {
-        *reinterpret_cast<uint32_t *>(p) =
-            (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        *reinterpret_cast<uint32_t *>(p) = f32x2_to_bf16x2(v[0], v[1]);
     }
 };
 template <>
@@ -582,6 +581,9 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
     int gsel = 64;
     for (int gg = 1; gg <= 64; gg <<= 1)
         if ((nv + gg - 1) / gg <= 8) { gsel = gg; break; }
+    // 64-row tiles (G = 4) measured best whenever a row has at least 8 vectors (fp32 C = 100:
+    // 10.8 us against 11.8 for G = 8; bf16 C = 104: 8.7 us against 12.3 for G = 2)
+    if (gsel < 4 && nv >= 8) gsel = 4;
     if (force_g && (nv + force_g - 1) / force_g <= 8) gsel = force_g;
     const int k = (nv + gsel - 1) / gsel;
     if (k > 8) return RLVI_E_LIMIT;

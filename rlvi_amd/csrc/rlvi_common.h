@@ -187,11 +187,16 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
     return __uint_as_float((uint32_t)h << 16);
 }
-// round-to-nearest-even, NaN kept NaN (plain cast semantics)
+// round-to-nearest-even, NaN kept NaN: the plain cast, which hipcc lowers to v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+// two values in one v_cvt_pk_bf16_f32: lo in bits 15:0, hi in bits 31:16
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
 }  // namespace rlvi

@@ -1,3 +1,7 @@
 #!/bin/bash
-python tools/time_parts.py --what thr --tag "threshold+truncate N=65536" 2>&1 | tail -1
-python tools/time_parts.py --what thr --n 8192 --tag "threshold+truncate N=8192" 2>&1 | tail -1
+for g in 4 8; do for nb in 768 1024 1536 2048; do
+RLVI_MSTEP_G=$g RLVI_MSTEP_BLOCKS=$nb python tools/time_parts.py --what mstep --tag "f32 C=100 G=$g blocks=$nb" 2>/dev/null | tail -1
+done; done
+for g in 2 4 8; do for nb in 512 768 1024; do
+RLVI_MSTEP_G=$g RLVI_MSTEP_BLOCKS=$nb python tools/time_parts.py --what mstep --classes 104 --dtype bf16 --tag "bf16 C=104 G=$g blocks=$nb" 2>/dev/null | tail -1
+done; done
