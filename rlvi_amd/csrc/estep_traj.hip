@@ -496,6 +496,8 @@ int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxi
                        tol, K, S, out_iters, trace, ws, mstep_out, mstep_scale, dbg)
     if (L <= (int64_t)TJ_BLOCK * 4) RLVI_TJ(4);
     else if (L <= (int64_t)TJ_BLOCK * 12) RLVI_TJ(12);
+    else if (L <= (int64_t)TJ_BLOCK * 16) RLVI_TJ(16);     // (spills a few registers; still far
+                                                           //  ahead of re-streaming the slice)
     else RLVI_TJ(0);
 #undef RLVI_TJ
     *rc = (int)hipGetLastError();

@@ -335,6 +335,40 @@ def test_estep_trajectory_cold_warm_and_poor_guess(gpu, oracle):
     assert ws.status() == 0
 
 
+def test_threshold_randomised_ties_and_ranges(gpu, oracle):
+    """Randomised sweep of the threshold / truncation / mask kernels against the oracle: heavy
+    ties (quantised weights), exact 0 / 1 plateaus, tiny and ragged sizes, monotone `max` with the
+    previous threshold, and out-of-[0,1] weights (generic fp64 path).  Everything bit-exact."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        N = int(rng.choice([1, 2, 3, 17, 64, 65, 1000, 1024, 1025, 5000, 16384, 16385, 40000, 65536, 70000]))
+        kind = trial % 5
+        if kind == 0:
+            w = rng.random(N).astype(np.float32)
+        elif kind == 1:
+            w = (rng.integers(0, 8, N) / 7.0).astype(np.float32)             # 8 distinct values
+        elif kind == 2:
+            w = np.where(rng.random(N) < 0.5, 1.0, rng.random(N) ** 4).astype(np.float32)
+        elif kind == 3:
+            w = np.where(rng.random(N) < 0.3, 0.0, rng.random(N)).astype(np.float32)
+        else:
+            w = (rng.random(N) * 1.5 - 0.2).astype(np.float32)               # outside [0, 1]
+        alpha = float(rng.choice([0.05, 0.01, 0.5, 0.0]))
+        prev = float(rng.choice([0.0, 0.0, 0.3, 0.99]))
+        thr_ref = oracle.false_negative_criterion(w, alpha=alpha)
+        wt = torch.from_numpy(w.copy()).to(dev)
+        assert float(ops.fn_threshold(wt, alpha=alpha)) == float(thr_ref), (trial, N, kind, alpha)
+        thr2, mask, kept = ops.threshold_truncate(wt, prev, alpha=alpha, want_mask=True)
+        expect = max(np.float32(prev), thr_ref)
+        assert float(thr2) == float(expect), (trial, N, kind, alpha)
+        w2 = w.copy()
+        m_ref = oracle.truncate(w2, expect)
+        assert np.array_equal(wt.cpu().numpy(), w2), (trial, N, kind)
+        assert np.array_equal(mask.cpu().numpy(), m_ref) and int(kept) == int(m_ref.sum())
+    assert dev_status(ops, dev) == 0
+
+
 def test_estep_maxiter_cap_and_tol(gpu, oracle):
     torch, ops, dev = gpu
     N = 5000
