@@ -13,14 +13,20 @@
 // recurrence with the first-order correction S(r_k) ~ S(r'_k) + S'(r'_k)(r_k - r'_k).  The
 // corrected r_k become the next round's nodes.  Node 0 is exact, a node whose predecessor was
 // exact becomes exact, so m rounds fix at least m nodes (worst case = the iterative scheme); the
-// correction is Newton-like (second-order remainder <= 0.25 (dr/r)^2), so from the previous
-// call's trajectory (kept in the workspace) it takes 3 rounds, from a cold geometric guess 5-6.
-// A round is accepted when max_k |r_k - r'_k| / r'_k <= 1e-6 over the executed iterations: then
-// S is exact to ~1e-12 and D (evaluated AT the nodes) to ~4e-6 relative, i.e. the stop decision
-// differs from the reference's only where its own fp32 rounding would decide it.
+// correction is Newton-like (second-order remainder <= 0.25 (dr/r)^2) and damped to a +-50 % trust
+// region, so from the previous call's trajectory (kept in the workspace) it takes 2-3 rounds, from
+// a cold or poor guess 4-9.  A round is accepted when max_k |r_k - r'_k| / r'_k <= 1e-6 over the
+// executed iterations (S exact to ~1e-12, D -- evaluated AT the nodes -- to ~4e-6 relative), or
+// earlier when every stop test clears tol by 8x the uncertainty the remaining delta implies.
+// The minimum residual is not exchanged separately: round 0 evaluates with the previous call's
+// minimum as the shift (e' = e * exp(shift - min) only rescales the nodes) and carries the true
+// minimum in its records.
 //
-// Sums: fp32 per thread (<= 16 terms), fp64 across threads / workgroups in a fixed order: every
-// workgroup computes bit-identical totals and the same scalar recurrence -- deterministic.
+// Sums: fp32 per thread and wave, fp64 across waves / workgroups in a fixed order: every workgroup
+// computes bit-identical totals and the same scalar recurrence.  Identical inputs AND workspace
+// state give identical bits; a different warm start may move pi by one ulp.
+// RLVI_TJ_DEBUG=1 makes workgroup 0 write wall-clock stamps of its phases into the workspace
+// scratch (tools/time_parts.py prints them); the stamps never feed a result.
 #include <stdlib.h>
 
 #include "rlvi_coop.h"
@@ -54,16 +60,13 @@ struct TjShared {
 };
 
 // ---------------------------------------------------------------------------------------
-// One round's communication + the scalar recurrence, all on wave 0 (the other waves wait at the
-// closing barrier).  Workgroup b = k*S + s publishes {S, S', D, min} as 8 self-tagged granules;
-// lane k of wave 0 polls the S records of node k, so the per-node totals land in the lane that
-// runs node k's part of the recurrence: no LDS staging, no second reduction stage.
-// Protocol as in rlvi_coop.h (sc1 stores / loads, parity slots, tags from the workspace base).
+// One round's communication + the scalar recurrence.  Workgroup b = k*S + s publishes
+// {S, S', D, min} as 8 self-tagged granules; waves 0..3 sweep the K*S records (one 64-byte record
+// per lane, four 16-byte sc1 loads in flight) into LDS; lane k of wave 0 adds node k's S records in
+// slice order and runs node k's part of the recurrence (the other waves wait at the closing
+// barrier).  Protocol as in rlvi_coop.h (sc1 stores / loads, parity slots, tags from the
+// workspace base, wall-clock-bounded spins).
 // ---------------------------------------------------------------------------------------
-struct TjRound {
-    float rn;         // node the sums were evaluated at (r-space), per lane
-    float scale;      // exp(min - shift): converts the evaluated nodes to r-space (round 0 only)
-};
 
 template <bool FIRST>
 __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float fD, float fmin_,
