@@ -66,6 +66,10 @@ int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream);
  *   out         [4] fp32 device: { sum_i pi_i*l_i * inv_scale, 100*hits/B, sum_i pi_i*l_i, hits }
  * bf16 variant: logits / grad_logits are bfloat16, arithmetic is fp32 on the widened values.
  *
+ * Evaluation form: weights == NULL (then idx and residuals must be NULL too) computes the plain
+ * mean CE and the top-1 percentage of the batch -- utils.evaluate (deep-learning/utils.py:48-62)
+ * without a separate softmax / argmax pass.
+ *
  * out == NULL selects ACCUMULATE mode: nothing is finalised; every workgroup adds its partial sums
  * {loss_b, top-1 % of the batch, sum pi*l, hits} to its own record in the workspace (no atomics),
  * so a whole epoch of mini-batches costs one launch each, and rlvi_epoch_end_f32 (or

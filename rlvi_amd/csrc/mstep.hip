@@ -210,7 +210,7 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
         if (y64 < 0 || y64 >= C) { y64 = 0; bad = bad || valid; row_ok = false; }
         if (ix < 0 || ix >= N) { ix = 0; bad = bad || valid; row_ok = false; }
         const int y = (int)y64;
-        const float pi = weights[ix];
+        const float pi = weights != nullptr ? weights[ix] : 1.0f;   // no weights: plain CE
         // the label logit again (one 4-byte read of a line this wave has just requested)
         float zy;
         {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(MSTEP_THREADS, RLVI_MSTEP_MINWAVES) void mstep_tile
             bool okrow = true;
             if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
             if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
-            const float pi = weights[ix];
+            const float pi = weights != nullptr ? weights[ix] : 1.0f;   // no weights: plain CE
             __builtin_amdgcn_sched_barrier(0);
             if (tid < TR) {
                 s_ix[tid] = ix;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(MSTEP_THREADS, RLVI_MSTEP_MINWAVES) void mstep_tile
             bool okrow = true;
             if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
             if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
-            const float pi = weights[ix];
+            const float pi = weights != nullptr ? weights[ix] : 1.0f;   // no weights: plain CE
             if (tid < rows_here) {
                 s_ix[tid] = ix;
                 s_pi[tid] = pi;
@@ -607,7 +607,9 @@ template <typename T>
 static int mstep_entry(const T *logits, int64_t ld, const int64_t *labels, const int64_t *idx,
                        const float *weights, float *residuals, int64_t N, int64_t B, int64_t C,
                        float inv_scale, T *grad, int64_t ldg, float *out, void *ws, void *stream) {
-    if (!logits || !labels || !weights || !ws) return RLVI_E_NULL;
+    if (!logits || !labels || !ws) return RLVI_E_NULL;
+    if (!weights && idx) return RLVI_E_NULL;       // an index without the vector it indexes
+    if (!weights) N = B;                            // evaluation form: identity rows, pi = 1
     if (B <= 0 || C <= 0 || N <= 0 || ld < C || (grad && ldg < C)) return RLVI_E_SHAPE;
     if (C > (1 << 20)) return RLVI_E_LIMIT;
     if (((uintptr_t)labels & 7) || ((uintptr_t)idx & 7) || ((uintptr_t)weights & 3) ||

@@ -73,13 +73,15 @@ class IndexedLoader:
 @torch.no_grad()
 def evaluate(loader, model, device):
     """utils.evaluate (deep-learning/utils.py:48-62): top-1 accuracy in percent."""
+    from . import ops
     model.eval()
-    correct = total = 0
+    hits = torch.zeros((), device=device)
+    total = 0
     for images, labels, _ in loader:
-        pred = model(images.to(device)).argmax(1)
-        correct += int((pred == labels.to(device)).sum())
+        out = ops.evaluate_batch(model(images.to(device)), labels.to(device))   # one pass: CE + top-1
+        hits += out[3]
         total += labels.numel()
-    return 100.0 * correct / total
+    return 100.0 * float(hits) / total
 
 
 def get_ratio_corrupted(mask, noise_mask):

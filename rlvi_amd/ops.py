@@ -127,6 +127,27 @@ def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None,
     _lib.check(rc, "rlvi_estep_deep_f32")
 
 
+def evaluate_batch(logits, labels, out=None, ws=None):
+    """Plain cross-entropy mean and top-1 percentage of one batch in one streaming pass over the
+    logits (utils.evaluate, deep-learning/utils.py:48-62): out fp32[4] = {mean CE, top-1 %, sum
+    CE, hits}."""
+    L = _lib.load()
+    _require_gpu(logits, labels)
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    labels = labels.to(torch.int64).contiguous()
+    B, C = logits.shape
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    ws = ws or workspace(logits.device, B, B)
+    fn = L.rlvi_mstep_fwd_bwd_f32 if logits.dtype == torch.float32 else L.rlvi_mstep_fwd_bwd_bf16
+    _lib.check(fn(_ptr(logits), logits.stride(0), _ptr(labels), None, None, None, B, B, C, 1.0 / B,
+                  None, 0, _ptr(out), ws.ptr, _stream_ptr()), "rlvi_mstep_fwd_bwd (evaluation form)")
+    return out
+
+
 def mstep_reduce(scale=1.0, out=None, ws=None, device=None):
     """Collect (and clear) the records of accumulate-mode M-step calls -> out fp32[4]."""
     L = _lib.load()

@@ -117,6 +117,18 @@ def test_mstep_strided_rows_and_forward_only(gpu, oracle):
     assert np.abs(diff).max() <= 1e-6
 
 
+def test_evaluation_form_matches_torch(gpu):
+    """weights == NULL: plain CE mean + top-1 (utils.evaluate) against torch's own ops."""
+    torch, ops, dev = gpu
+    d = synth.mstep_inputs(3000, 37, seed=8)
+    z, y = torch.from_numpy(d["logits"]).to(dev), torch.from_numpy(d["labels"]).to(dev)
+    out = ops.evaluate_batch(z, y)
+    ce = torch.nn.functional.cross_entropy(z, y)
+    acc = (z.argmax(1) == y).float().mean() * 100
+    assert abs(float(out[0]) - float(ce)) <= 1e-5 * float(ce)
+    assert float(out[1]) == pytest.approx(float(acc), abs=1e-3)
+
+
 def test_mstep_out_of_range_sets_status_and_touches_nothing(gpu):
     torch, ops, dev = gpu
     B, C = 64, 10
