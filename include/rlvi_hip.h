@@ -42,6 +42,7 @@ extern "C" {
 #define RLVI_ST_RANGE   1  /* a label or index was out of range (row skipped)      */
 #define RLVI_ST_TIMEOUT 2  /* an inter-workgroup wait hit its bound (results invalid) */
 #define RLVI_ST_NOCONV  4  /* the trajectory E-step did not reach its fixed point (results invalid) */
+#define RLVI_ST_SINGULAR 8 /* weighted least squares: Gram matrix not positive definite (theta = NaN) */
 
 int rlvi_abi_version(void);
 const char *rlvi_error_string(int code);
@@ -158,6 +159,12 @@ int rlvi_update_weights_online_f64(const double *losses, int64_t n, double tol, 
  *   rlvi_logistic_nll_f64   online-learning/main.py:295-296,:84-85: -log sigmoid(X w + b)
  * X is row-major [n, d].
  * ------------------------------------------------------------------------------------- */
+/* Weighted least squares theta = argmin sum_i w_i (y_i - x_i.theta)^2, the M-step of
+ * linear_regression (standard-learning/rlvi.py:70-71,:79-80, scipy lstsq on diag(sqrt(w))-scaled
+ * rows there): [X | y]^T W [X | y] on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), Cholesky +
+ * triangular solves in one workgroup.  d <= 63, X of full column rank. */
+int rlvi_wls_solve_f64(const double *X, const double *y, const double *w, int64_t n, int64_t d,
+                       double *theta, void *ws, void *stream);
 int rlvi_linreg_losses_f64(const double *X, const double *y, const double *theta,
                            const double *w, int64_t n, int64_t d, double *losses,
                            double *sigma2_out, void *ws, void *stream);

@@ -38,6 +38,7 @@ SIGNATURES = {
                                  _vp, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_update_weights_f64": (_int, [_vp, _i64, _f64, _int, _vp, _vp, _vp, _vp]),
     "rlvi_update_weights_online_f64": (_int, [_vp, _i64, _f64, _int, _vp, _vp, _vp, _vp]),
+    "rlvi_wls_solve_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "rlvi_linreg_losses_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_logistic_nll_f64": (_int, [_vp, _vp, _f64, _i64, _i64, _vp, _vp]),
 }

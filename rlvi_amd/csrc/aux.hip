@@ -26,7 +26,9 @@ extern "C" int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream) {
     if (!ws) return RLVI_E_NULL;
     if (((uintptr_t)ws & 255)) return RLVI_E_ALIGN;
     if (ws_bytes < WS_SCRATCH_OFF) return RLVI_E_WS;
-    return (int)hipMemsetAsync(ws, 0, WS_SCRATCH_OFF, static_cast<hipStream_t>(stream));
+    // control words, exchange slots, warm-start state, M-step records (the WLS / scratch regions
+    // behind them need no initial value)
+    return (int)hipMemsetAsync(ws, 0, WS_WLS_OFF, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream) {

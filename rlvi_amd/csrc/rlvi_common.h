@@ -37,7 +37,11 @@ constexpr size_t WS_PART_OFF = WS_TRAJ_OFF + WS_TRAJ_BYTES;
 constexpr int MSTEP_MAX_BLOCKS = 1024;
 constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
 constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
-constexpr size_t WS_SCRATCH_OFF = WS_PART_OFF + WS_PART_BYTES;
+// partial Gram matrices of the weighted-least-squares kernel: 8 workgroups x 64 x 64 doubles
+constexpr size_t WS_WLS_OFF = WS_PART_OFF + WS_PART_BYTES;
+constexpr int WLS_MAX_WG = 8;
+constexpr size_t WS_WLS_BYTES = (size_t)WLS_MAX_WG * 64 * 64 * 8;               // 256 KiB
+constexpr size_t WS_SCRATCH_OFF = WS_WLS_OFF + WS_WLS_BYTES;
 
 __host__ __device__ inline size_t ws_bytes_for(int64_t max_n, int64_t max_b) {
     // scratch: two fp32 vectors of max(max_n, max_b) (fused E+M keeps l and e there)

@@ -266,6 +266,22 @@ def update_weights_f64(losses, tol=1e-3, maxiter=100, online=False):
     return out, iters
 
 
+def wls_solve(X, y, w, theta=None):
+    """theta = argmin sum w_i (y_i - x_i.theta)^2 on the device (rlvi.py:70-71,:79-80): weighted Gram
+    matrix on the fp64 MFMA units + Cholesky solve.  X [n, d <= 63] of full column rank."""
+    L = _lib.load()
+    _require_gpu(X, y, w)
+    X = X.to(torch.float64).contiguous()
+    n, d = X.shape
+    if theta is None:
+        theta = torch.empty(d, dtype=torch.float64, device=X.device)
+    ws = workspace(X.device, n, 0)
+    _lib.check(L.rlvi_wls_solve_f64(_ptr(X), _ptr(y.to(torch.float64).contiguous()),
+                                    _ptr(w.to(torch.float64).contiguous()), n, d, _ptr(theta),
+                                    ws.ptr, _stream_ptr()), "rlvi_wls_solve_f64")
+    return theta
+
+
 def linreg_losses(X, y, theta, w):
     """rlvi.py:72-74: losses = 0.5 (y - X theta)^2 / sigma2, sigma2 = w.r / sum(w)."""
     L = _lib.load()

@@ -7,8 +7,9 @@
     logistic_regression(X, y, maxiter=100, tol=1e-2) -> theta  reference rlvi.py:92-108
 
 The E-step fixed point and the per-sample NLL (the X.theta contraction) run in
-librlvi_gfx950.so; the weighted solvers stay third-party as in the reference (scipy lstsq /
-sklearn liblinear there; torch.linalg.lstsq on the device / sklearn liblinear here).
+librlvi_gfx950.so, and so does the weighted least-squares solve of linear_regression (normal
+equations on the fp64 MFMA units + Cholesky); logistic regression keeps sklearn's liblinear on
+the host, as the reference has it.
 Host arrays cross PCIe once per call; use rlvi_amd.ops directly to keep data resident.
 """
 import numpy as np
@@ -32,8 +33,12 @@ def update_weights(losses, tol=1e-3, maxiter=100):
 
 
 def _wls(X, y, w):
-    """theta = argmin sum_i w_i (y_i - x_i.theta)^2 via sqrt(w)-scaled rows (rlvi.py:70-71,79-80;
-    the reference materialises the n x n diag(sqrt(w)), the product is the same matrix)."""
+    """theta = argmin sum_i w_i (y_i - x_i.theta)^2 (rlvi.py:70-71,79-80; the reference materialises
+    the n x n diag(sqrt(w)) and calls scipy lstsq).  Here: the weighted Gram matrix on the fp64
+    matrix cores + a Cholesky solve, all on the device (rlvi_wls_solve_f64); d > 63 falls back to
+    torch.linalg.lstsq on the sqrt(w)-scaled rows."""
+    if X.shape[1] <= 63:
+        return ops.wls_solve(X, y, w)
     sw = torch.sqrt(w)
     sol = torch.linalg.lstsq(sw[:, None] * X, (sw * y)[:, None])
     return sol.solution[:, 0]

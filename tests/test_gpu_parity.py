@@ -448,6 +448,34 @@ def test_update_weights_f64_vs_oracle(n, gpu, oracle):
         np.testing.assert_allclose(w.cpu().numpy(), ref, rtol=1e-10, atol=1e-300)
 
 
+@pytest.mark.parametrize("n,d", [(40, 10), (1000, 20), (5000, 63), (17, 1), (300, 15), (9000, 31)])
+def test_wls_solve_mfma_vs_lstsq(n, d, gpu):
+    """Weighted least squares on the fp64 matrix cores + Cholesky against numpy lstsq on the
+    sqrt(w)-scaled rows (what the reference's scipy call solves)."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(n + d)
+    X = -5 + 10 * rng.random((n, d))
+    y = X @ rng.standard_normal(d) + 0.3 * rng.standard_normal(n)
+    w = rng.random(n) ** 3
+    sw = np.sqrt(w)
+    ref = np.linalg.lstsq(sw[:, None] * X, sw * y, rcond=None)[0]
+    got = ops.wls_solve(*(torch.from_numpy(a).to(dev) for a in (X, y, w))).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-11)
+    assert dev_status(ops, dev) == 0
+
+
+def test_wls_singular_sets_status(gpu):
+    torch, ops, dev = gpu
+    X = np.ones((50, 3))                       # rank 1
+    y = np.arange(50.0)
+    ws = ops.workspace(dev)
+    th = ops.wls_solve(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev), torch.ones(50, dtype=torch.float64, device=dev))
+    assert torch.isnan(th).all() and (ws.status() & 8)
+    from rlvi_amd import _lib
+    _lib.check(_lib.load().rlvi_workspace_init(ws.ptr, ws.nbytes, None), "init")
+    torch.cuda.synchronize()
+
+
 def test_linreg_and_logistic_nll(gpu, oracle):
     torch, ops, dev = gpu
     X, y = synth.linreg_data(1000, 20, seed=0)
