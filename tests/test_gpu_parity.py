@@ -381,6 +381,32 @@ def test_threshold_randomised_ties_and_ranges(gpu, oracle):
     assert dev_status(ops, dev) == 0
 
 
+def test_estep_cooperative_under_concurrent_load(gpu, oracle):
+    """The cooperative E-step needs its ~240 workgroups co-resident.  With another stream keeping
+    every CU busy (back-to-back GEMMs) its workgroups arrive unevenly; the exchange must neither
+    hang nor go stale: status stays 0 and the result is the oracle's."""
+    torch, ops, dev = gpu
+    N = 65536
+    r = synth.residual_vector("bimodal", N, seed=3)
+    rr, ww = r.copy(), np.ones(N, np.float32)
+    it = oracle.update_sample_weights(rr, ww)
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    ws = ops.Workspace(dev, N, 0)
+    for trial in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                a @ a                                   # ~0.1 ms each, all CUs
+        rt, wt = torch.from_numpy(r.copy()).to(dev), torch.ones(N, device=dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=iters, ws=ws)
+        torch.cuda.synchronize()
+        assert ws.status() == 0
+        assert int(iters) == it
+        rel, small = rel_pi(wt.cpu().numpy(), ww)
+        assert rel <= REL and small <= 1e-7
+
+
 def test_estep_maxiter_cap_and_tol(gpu, oracle):
     torch, ops, dev = gpu
     N = 5000
