@@ -384,8 +384,19 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
                 }
             }
         } else {
-            for (int64_t i = lo + tid; i < hi; i += TJ_BLOCK)
-                body(expf(-(res[i] - cshift)), k == 0 ? wts[i] : 0.0f);
+            // streaming form: four independent loads in flight per thread
+            for (int64_t i = lo + tid; i < hi; i += 4 * TJ_BLOCK) {
+                float lv[4], wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t ii = i + (int64_t)u * TJ_BLOCK;
+                    lv[u] = ii < hi ? res[ii] : __builtin_inff();
+                    wv[u] = (k == 0 && ii < hi) ? wts[ii] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + (int64_t)u * TJ_BLOCK < hi) body(expf(-(lv[u] - cshift)), wv[u]);
+            }
         }
         TJ_STAMP();   // sums done
         if (round == 0)
@@ -481,7 +492,11 @@ int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxi
                           int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                           float *mstep_out, double mstep_scale, int *rc) {
     static const int mode = getenv("RLVI_ESTEP_TRAJ") ? atoi(getenv("RLVI_ESTEP_TRAJ")) : 1;
-    if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < 4096) return 0;
+    // Beyond ~200k samples a round (K evaluations per sample, slices streamed from L2) costs more
+    // than the iterations it replaces: measured 43 vs 68 us at N = 262144 for ONE round, 74 vs 74 us
+    // at 524288 -- with the usual two rounds the iterative kernel wins there.
+    static const int64_t nmax = getenv("RLVI_ESTEP_TRAJ_NMAX") ? atoll(getenv("RLVI_ESTEP_TRAJ_NMAX")) : 200000;
+    if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < 4096 || N > nmax) return 0;
     const int K = maxiter;
     int S = (MAX_COOP_WG - 1) / K;
     if (S < 1) return 0;
