@@ -124,8 +124,8 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
             w[j] = nw;
         }
         double sse = (double)sse_t, sum = (double)sum_t;
-        co.template allreduce2<OpSum, OpSum>(sse, sum);
-        const F err = (F)sqrt(sse);                   // ||new - weights||_2
+        co.template allreduce2<OpSum, OpSum, sizeof(F) == 4>(sse, sum);
+        const F err = sizeof(F) == 4 ? (F)sqrtf((float)sse) : (F)sqrt(sse);   // ||new - weights||_2
         const F avg = (F)sum / (F)N;                  // mean(weights)
         if (trace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
             trace[2 * it] = err;

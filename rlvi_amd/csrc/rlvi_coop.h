@@ -24,6 +24,7 @@ namespace rlvi {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef unsigned int vu4_t __attribute__((ext_vector_type(4)));
 
 struct OpSum {
     static __device__ __forceinline__ double ident() { return 0.0; }
@@ -41,6 +42,16 @@ struct OpMax {
 template <class Op>
 struct OpFn {
     __device__ __forceinline__ double operator()(double a, double b) const { return Op::apply(a, b); }
+};
+template <class Op>
+struct OpFnF {
+    __device__ __forceinline__ float operator()(float a, float b) const {
+        return (float)Op::apply((double)a, (double)b);
+    }
+};
+template <>
+struct OpFnF<OpSum> {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
 };
 template <class Op>
 __device__ __forceinline__ double wave_reduce(double v) {
@@ -83,15 +94,23 @@ struct Coop {
     }
 
     // All threads call with their per-thread partials; all threads return the global result.
-    template <class OpA, class OpB>
+    // F32WAVE: the per-thread partials are fp32 values; reduce them inside the wave in fp32 (one
+    // fused v_add_f32_dpp per butterfly step instead of two DPP moves + an fp64 add), fp64 from
+    // the wave partials on.
+    template <class OpA, class OpB, bool F32WAVE = false>
     __device__ __forceinline__ void allreduce2(double &a, double &b) {
         __shared__ double part[2 * NW];
         __shared__ double bc[2];
         __shared__ int sh_dead;
         const int lane = threadIdx.x & (WAVE - 1);
         const int wave = threadIdx.x / WAVE;
-        a = wave_reduce<OpA>(a);
-        b = wave_reduce<OpB>(b);
+        if (F32WAVE) {
+            a = (double)group_allreduce<WAVE>((float)a, OpFnF<OpA>());
+            b = (double)group_allreduce<WAVE>((float)b, OpFnF<OpB>());
+        } else {
+            a = wave_reduce<OpA>(a);
+            b = wave_reduce<OpB>(b);
+        }
         if (lane == 0) { part[2 * wave] = a; part[2 * wave + 1] = b; }
         __syncthreads();
         if (wave == 0) {
@@ -121,10 +140,20 @@ struct Coop {
                     for (unsigned spin = 0;; ++spin) {
                         bool ok = true;
                         if (mine) {
-                            x0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            x1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            x2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            x3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // the 32-byte record as two 16-byte sc1 loads (granule-atomic is enough:
+                            // every 8-byte granule carries its own tag)
+                            vu4_t q0, q1;
+                            asm volatile(
+                                "global_load_dwordx4 %0, %2, off sc1\n\t"
+                                "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                                "s_waitcnt vmcnt(0)"
+                                : "=&v"(q0), "=&v"(q1)
+                                : "v"((unsigned long long)(uintptr_t)p)
+                                : "memory");
+                            x0 = ((unsigned long long)q0.y << 32) | q0.x;
+                            x1 = ((unsigned long long)q0.w << 32) | q0.z;
+                            x2 = ((unsigned long long)q1.y << 32) | q1.x;
+                            x3 = ((unsigned long long)q1.w << 32) | q1.z;
                             ok = (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag &&
                                  (uint32_t)(x2 >> 32) == tag && (uint32_t)(x3 >> 32) == tag;
                         }

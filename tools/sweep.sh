@@ -1,5 +1,4 @@
 #!/bin/bash
-for n in 131072 262144 524288; do
-python tools/time_parts.py --what estep --n $n --steps 50 --tag "traj N=$n" 2>/dev/null | tail -1
-RLVI_ESTEP_TRAJ=0 python tools/time_parts.py --what estep --n $n --steps 50 --tag "iterative N=$n" 2>/dev/null | tail -1
-done
+python tools/time_parts.py --what estep --n 2048 --steps 50 --tag "iterative N=2048 (1 WG)" 2>/dev/null | tail -1
+RLVI_ESTEP_TRAJ=0 python tools/time_parts.py --what estep --n 65536 --steps 50 --tag "iterative N=65536" 2>/dev/null | tail -1
+python tools/time_parts.py --what estep --n 524288 --steps 50 --tag "iterative N=524288" 2>/dev/null | tail -1
