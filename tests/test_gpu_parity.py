@@ -408,6 +408,34 @@ def test_estep_cooperative_under_concurrent_load(gpu, oracle):
         assert rel <= REL and small <= 1e-7
 
 
+def test_estep_bench_size_properties(gpu):
+    """Size-independent E-step properties at the BASELINE size (65 536) on the HIP path: max pi is
+    exactly 1, pi is non-increasing in the loss, the min shift is exact, the caller's weights do
+    not influence the result beyond the first error (same iteration count -> same pi to 1 ulp)."""
+    torch, ops, dev = gpu
+    N = 65536
+    d = synth.mstep_inputs(N, 100)
+    rng = np.random.default_rng(0)
+    res = torch.zeros(N, device=dev)
+    ops.mstep_fwd_bwd(torch.from_numpy(d["logits"]).to(dev), torch.from_numpy(d["labels"]).to(dev),
+                      torch.from_numpy(d["idx"]).to(dev), torch.from_numpy(d["weights"]).to(dev), res,
+                      want_grad=False)
+    r0 = res.cpu().numpy()
+    outs = []
+    for w_in in (np.ones(N, np.float32), rng.random(N).astype(np.float32)):
+        rt, wt = torch.from_numpy(r0.copy()).to(dev), torch.from_numpy(w_in).to(dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=iters, ws=ops.Workspace(dev, N, 0))
+        outs.append((rt.cpu().numpy(), wt.cpu().numpy(), int(iters)))
+    r1, w1, it1 = outs[0]
+    assert w1.max() == np.float32(1.0) and w1.min() >= 0 and np.all(np.isfinite(w1))
+    assert np.array_equal(r1, r0 - r0.min())
+    order = np.argsort(r0, kind="stable")
+    assert np.all(np.diff(w1[order]) <= 1e-7)
+    if outs[1][2] == it1:
+        np.testing.assert_allclose(outs[1][1], w1, rtol=5e-7, atol=1e-37)
+
+
 def test_estep_maxiter_cap_and_tol(gpu, oracle):
     torch, ops, dev = gpu
     N = 5000
