@@ -150,7 +150,7 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
             // pi is increasing in e and the min-shifted residual 0 gives e = 1 exactly, so the
             // maximum is the value every thread can compute alone -- no exchange
             const F t1 = ratio_used * (F)1;
-            mx = t1 / ((F)1 + t1);
+            mx = fdiv(t1, (F)1 + t1);     // the very expression used per element: pi_max / mx == 1
         } else {
             double a = (double)mx, b = 0.0;
             co.template allreduce2<OpMax, OpSum>(a, b);

@@ -440,8 +440,10 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
     if (!accepted && tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
 
     // ---- weights = pi / max(pi); max is attained at e = 1 (the min-residual sample) (:38)
-    const float tmax = r_fin;
-    const float inv_pmax = (1.0f + tmax) * __builtin_amdgcn_rcpf(tmax);
+    // f_max is evaluated with the very expression used per element and the normalisation is a
+    // true division, so the min-residual sample (e = 1) comes out as exactly 1.0, as div_(max) does
+    const float tmax = r_fin * 1.0f;
+    const float pmax = tmax * __builtin_amdgcn_rcpf(1.0f + tmax);
     // workgroup (k, s) writes the elements of slice s whose position is congruent to k mod K
     // (position mod K advances by 1024 mod K per step: no per-element division)
     {
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
                 if (j < cnt && pm == k) {
                     const int64_t i = lo + tid + (int64_t)j * TJ_BLOCK;
                     const float t = r_fin * e[j];
-                    wts[i] = t * __builtin_amdgcn_rcpf(1.0f + t) * inv_pmax;
+                    wts[i] = (t * __builtin_amdgcn_rcpf(1.0f + t)) / pmax;
                 }
                 pm += stepm;
                 pm = pm >= K ? pm - K : pm;
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
                     const float l = res[i] - gmin;
                     const float t = r_fin * expf(-l);
                     res[i] = l;
-                    wts[i] = t * __builtin_amdgcn_rcpf(1.0f + t) * inv_pmax;
+                    wts[i] = (t * __builtin_amdgcn_rcpf(1.0f + t)) / pmax;
                 }
                 pm += stepm;
                 pm = pm >= K ? pm - K : pm;

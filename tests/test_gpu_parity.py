@@ -321,6 +321,7 @@ def test_estep_vs_oracle_sizes(N, gpu, oracle):
         rel, small = rel_pi(outs[0][1], ww)
         assert rel <= REL and small <= 1e-7
     assert np.array_equal(outs[0][0], rr)
+    assert outs[0][1].max() == np.float32(1.0)           # weights.div_(weights.max()) (:38)
 
 
 def test_estep_trajectory_cold_warm_and_poor_guess(gpu, oracle):
