@@ -21,7 +21,10 @@ enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
 int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxiter,
                           int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                           float *mstep_out, double mstep_scale, int *rc);
-
+// estep_trajb.hip: the same solver decomposed for large populations
+int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
+                           int32_t *out_iters, float *trace, void *ws, hipStream_t st,
+                           float *mstep_out, double mstep_scale, int *rc);
 
 // t/(1+t) etc.: fp32 uses v_rcp_f32 (1 ulp) + multiply instead of the ~15-instruction IEEE
 // division sequence: <= 2 ulp on pi, two orders of magnitude inside the 1e-5 parity budget, and
@@ -182,6 +185,9 @@ static int launch_estep(F *res, F *wts, int64_t N, F tol, int maxiter, int32_t *
                         double mstep_scale = 1.0) {
     if constexpr (VAR == VAR_DEEP) {
         int rc = 0;
+        if (try_launch_estep_trajb(res, wts, N, tol, maxiter, out_iters, trace, ws, st, mstep_out,
+                                   mstep_scale, &rc))
+            return rc;
         if (try_launch_estep_traj(res, wts, N, tol, maxiter, out_iters, trace, ws, st, mstep_out,
                                   mstep_scale, &rc))
             return rc;

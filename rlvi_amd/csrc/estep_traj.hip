@@ -29,7 +29,7 @@
 // scratch (tools/time_parts.py prints them); the stamps never feed a result.
 #include <stdlib.h>
 
-#include "rlvi_coop.h"
+#include "rlvi_traj.h"
 
 namespace rlvi {
 
@@ -37,26 +37,13 @@ typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
 
 constexpr int TJ_BLOCK = 1024;
 constexpr int TJ_NW = TJ_BLOCK / WAVE;
-constexpr int TJ_MAXK = 64;
-constexpr float TJ_ACCEPT = 1e-6f;
-
-struct TrajState {
-    long long n;
-    int k;
-    float shift;                 // min residual of the last call (guess of this call's shift)
-    float nodes[TJ_MAXK];
-};
-
 constexpr int TJ_MAXS = 8;       // slices per node (one lane of the polling wave sweeps them)
 
 struct TjShared {
     double part[TJ_NW][3];
     double rec[MAX_COOP_WG][4];   // gathered records (wave 0 only)
     float pmin[TJ_NW];
-    float nodes[TJ_MAXK];        // corrected trajectory of the latest round
-    int dead;
-    int res_it;
-    float res_delta, res_rfin, res_min;
+    TjOut out;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -152,7 +139,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             }
         }
         if (timeout) {
-            if (lane == 0) { atomicOr(status, RLVI_ST_TIMEOUT); sh.dead = 1; }
+            if (lane == 0) { atomicOr(status, RLVI_ST_TIMEOUT); sh.out.dead = 1; }
         } else if (mine) {
 #pragma unroll
             for (int q = 0; q < NQ / 2; ++q) sh.rec[w][q] = dbl(x[2 * q], x[2 * q + 1]);
@@ -161,7 +148,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
     TJ_RS(2);
     __syncthreads();
     TJ_RS(3);
-    dead = dead || sh.dead != 0;
+    dead = dead || sh.out.dead != 0;
     if (wave == 0) {
         double tS = 0.0, tP = 0.0, tD = 0.0;
         float gmin = __builtin_inff();
@@ -175,120 +162,12 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             }
         }
         TJ_RS(4);
-        const bool has = lane < K;
-        float scale = 1.0f;
-        if (FIRST) {
-            gmin = group_allreduce<WAVE>(gmin, FMin());
-            // the sums were taken with e' = exp(-(l - shift)) = e * exp(shift - min): in r-space the
-            // evaluated nodes are rn * exp(shift - min); not trustworthy if that factor is extreme
-            // or a sum overflowed
-            scale = expf(shift - gmin);
-        }
-        const float rn = rn_l * scale;
-        // (a node far below the trajectory may legitimately have S = 0 after fp32 underflow)
-        bool finite = has ? (tS == tS && tP == tP && tD == tD && tS < 1e300 && tP < 1e300 && tD < 1e300)
-                          : true;
-        const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
-        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
-            if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tD); }
-            if (lane == 0) { dbg[102] = __ballot(finite); dbg[103] = __float_as_uint(scale); }
-        }
-
-        // lane-parallel: a0 = mean(pi) at the node, b = d mean / dr, err = ||new - old||_2
-        const float a0_l = has ? (float)tS * invN : 0.0f;                                // (:35)
-        const float b_l = has ? (float)(tP * (double)invN) : 0.0f;
-        const float err_l = has ? sqrtf((float)tD) : __builtin_inff();                   // (:33)
-        const unsigned long long stopmask = __ballot(has && err_l < tol);                // (:36)
-        const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : K;
-        const int steps = it_now + 2 < K ? it_now + 2 : K;      // a little lookahead
-        float r = (float)(0.95 / (1.0 - 0.95));
-        float rnew_l = rn;
-        float avg_l = 0.0f;
-        // serial chain; `step` is wave-uniform, so the per-node values come through v_readlane
-        // (SGPR lane select, no LDS):  avg = a0 + b (r - r'),  r <- avg / (1 - avg).
-        // Fast form first (five dependent fp32 operations per step); its steps are then checked
-        // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
-        // that left it (cold or poor guesses) is redone in the damped form.
-        {
-#pragma unroll 1
-            for (int step = 0; step < steps; ++step) {
-                const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
-                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
-                const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
-                if (lane == step) rnew_l = r;
-                const float avg = fmaf(bb, r - rns, a0);
-                if (lane == step) avg_l = avg;
-                r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
-            }
-        }
-        const bool inside = !(has && lane < steps) ||
-                            (fabsf(rnew_l - rn) <= 0.5f * rn && avg_l > 0.0f && avg_l < 0.999999f);
-        if (!__all(inside)) {
-            r = (float)(0.95 / (1.0 - 0.95));
-#pragma unroll 1
-            for (int step = 0; step < steps; ++step) {
-                const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
-                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
-                const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
-                if (lane == step) rnew_l = r;
-                // damped step: the linearisation is trusted within +-50% of the node (S is concave
-                // in r, so the extrapolated mean stays positive); mean(pi) < 1
-                const float h = 0.5f * rns;
-                const float d = fmaxf(fminf(r - rns, h), -h);
-                const float avg = fminf(fmaf(bb, d, a0), 0.999999f);
-                if (lane == step) avg_l = avg;
-                r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-30f);              // (:31)
-            }
-        }
-        TJ_RS(5);
-        // nodes beyond the lookahead: a fresh geometric tail from the last corrected node
-        {
-            const float last = __shfl(rnew_l, steps - 1, WAVE);      // all lanes take part
-            if (has && lane >= steps) rnew_l = last * exp2f(-(float)(lane - steps + 1));
-        }
-        float d_l = (has && lane < it_now) ? fabsf(rnew_l - rn) * __builtin_amdgcn_rcpf(rn) : 0.0f;
-        float delta_w = group_allreduce<WAVE>(d_l, FMax());
-        // Early accept: with nodes off by delta the corrected r are good to 0.25 delta^2, and the
-        // errors (evaluated AT the nodes) to about delta*(r_k + r_{k-1})/|r_k - r_{k-1}| relative.
-        // If every stop test up to `it` clears tol by 8x that margin, the stop index cannot change
-        // any more, and neither can pi: no verification round needed.  (Not when the caller asked
-        // for the error trace: that wants the errors themselves.)
-        const float rp_l = __shfl_up(rn, 1, WAVE);
-        if (delta_w > TJ_ACCEPT && delta_w <= 1e-3f && trace == nullptr) {
-            float u = 0.0f;
-            if (has && lane < it_now && lane > 0) {
-                const float gap = fabsf(rn - rp_l);
-                u = 8.0f * delta_w * (rn + rp_l) * __builtin_amdgcn_rcpf(fmaxf(gap, 1e-30f));
-            }
-            if (lane == 0) u = 128.0f * delta_w;            // D_0 is taken against the caller's pi
-            const bool unsafe = has && lane < it_now && fabsf(err_l - tol) <= u * err_l;
-            if (__ballot(unsafe) == 0ull) delta_w = 0.0f;
-        }
-        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
-            dbg[130 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
-            if (lane == 0) { dbg[128] = round_ok; dbg[129] = ((unsigned long long)it_now << 32) | __float_as_uint(delta_w); }
-        }
-        // guesses stay where sums in fp32 cannot underflow; an invalid round restarts from the
-        // geometric cold guess instead of re-evaluating the nodes that broke it
-        rnew_l = fminf(fmaxf(rnew_l, 1e-30f), 1e30f);
-        if (!round_ok) { delta_w = __builtin_inff(); rnew_l = 19.0f * exp2f(-(float)lane); }
-        if (has && want_nodes) sh.nodes[lane] = rnew_l;
-        if (trace != nullptr && blockIdx.x == 0 && lane < it_now && round_ok) {
-            trace[2 * lane] = err_l;
-            trace[2 * lane + 1] = avg_l;
-        }
+        tj_chain<FIRST>(sh.out, K, K, tS, tP, 0.0, tD, gmin, dead, rn_l, shift, invN, tol, trace,
+                        want_nodes, xstep, dbg);
         TJ_RS(6);
-        const float rfin_w = __shfl(rnew_l, it_now - 1, WAVE);   // all lanes take part
-        if (lane == 0) {
-            sh.res_it = it_now;
-            sh.res_delta = delta_w;
-            sh.res_rfin = rfin_w;
-            if (FIRST) sh.res_min = gmin;
-            sh.dead = dead ? 1 : 0;
-        }
     }
     __syncthreads();
-    dead = sh.dead != 0;
+    dead = sh.out.dead != 0;
 }
 
 // E > 0: the slice lives in registers (slice length <= 1024*E); E == 0: re-read from memory.
@@ -307,7 +186,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
         return;
     }
     __shared__ TjShared sh;
-    if (threadIdx.x == 0) sh.dead = 0;
+    if (threadIdx.x == 0) sh.out.dead = 0;
     char *wsb = static_cast<char *>(ws);
     WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
     gu64 *slots = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG2_OFF));
@@ -407,19 +286,19 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
                             shift, invN, tol, trace, true, dbg);
         ++tag; ++xstep;
         TJ_STAMP();   // exchange + recurrence done
-        it = sh.res_it;
-        r_fin = sh.res_rfin;
-        const float delta = sh.res_delta;
-        if (dbg != nullptr && blockIdx.x == 0 && tid == 0 && round < 24 && round == 0) { dbg[100] = __float_as_uint(sh.res_min); dbg[101] = __float_as_uint(sh.res_rfin); }
+        it = sh.out.res_it;
+        r_fin = sh.out.res_rfin;
+        const float delta = sh.out.res_delta;
+        if (dbg != nullptr && blockIdx.x == 0 && tid == 0 && round < 24 && round == 0) { dbg[100] = __float_as_uint(sh.out.res_min); dbg[101] = __float_as_uint(sh.out.res_rfin); }
         if (dbg != nullptr && blockIdx.x == 0 && tid == 0 && round < 24)
             dbg[64 + round] = ((unsigned long long)it << 32) | __float_as_uint(delta);
-        rn_l = lane < K ? sh.nodes[lane] : 1.0f;
+        rn_l = lane < K ? sh.out.nodes[lane] : 1.0f;
         if (lane == 0) rn_l = (float)(0.95 / (1.0 - 0.95));
         r_mine = __shfl(rn_l, k, WAVE);
         r_prev = k > 0 ? __shfl(rn_l, k - 1, WAVE) : 0.0f;
         if (round == 0) {
             // the true minimum is known now: residuals.sub_(min) (:27), e = exp(-residuals) (:28)
-            gmin = sh.res_min;
+            gmin = sh.out.res_min;
             cshift = gmin;
             if (E > 0) {
 #pragma unroll
@@ -431,7 +310,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
                 e_ready = true;
             }
         }
-        __syncthreads();          // sh.nodes / sh.res_* are rewritten next round
+        __syncthreads();          // sh.out.nodes / sh.out.res_* are rewritten next round
         if (delta <= TJ_ACCEPT) { accepted = true; break; }
         if (dead) break;
     }
@@ -481,6 +360,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
             state->n = (long long)N;
             state->k = K;
             state->shift = gmin;
+            state->it = it;
             __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -494,9 +374,8 @@ int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxi
                           int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                           float *mstep_out, double mstep_scale, int *rc) {
     static const int mode = getenv("RLVI_ESTEP_TRAJ") ? atoi(getenv("RLVI_ESTEP_TRAJ")) : 1;
-    // Beyond ~200k samples a round (K evaluations per sample, slices streamed from L2) costs more
-    // than the iterations it replaces: measured 43 vs 68 us at N = 262144 for ONE round, 74 vs 74 us
-    // at 524288 -- with the usual two rounds the iterative kernel wins there.
+    // (from 24 576 samples on estep_trajb.hip is tried first and wins; this bound only matters when
+    //  that kernel is switched off)
     static const int64_t nmax = getenv("RLVI_ESTEP_TRAJ_NMAX") ? atoll(getenv("RLVI_ESTEP_TRAJ_NMAX")) : 200000;
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < 4096 || N > nmax) return 0;
     const int K = maxiter;

@@ -1,0 +1,407 @@
+// Trajectory E-step for LARGE populations (train_rlvi.py:14-38; N from ~1e5 to 2e6 samples).
+//
+// Same mathematics as estep_traj.hip (rlvi_traj.h holds the shared recurrence): guessed nodes r'_k
+// of the whole fixed-point trajectory, per round the totals S(r'_k), dS/dr(r'_k), D(r'_k, r'_{k-1})
+// for all nodes, a first-order corrected scalar recurrence, repeat until the nodes stop moving.
+// What changes is the decomposition.  There a workgroup owns ONE node and a sixth of the samples,
+// which stops fitting registers near 1e5 samples; here every workgroup owns a small slice of the
+// samples (N/240, registers) and evaluates ALL live nodes on it:
+//   * eight nodes at a time: per-thread partials of {sum r e/(1+r e), sum e/(1+r e)^2, sum e^2/(1+r e)^3,
+//     sum d^2} (the recurrence corrects S to second order in the node error), then a
+//     transposing butterfly (v_permlane32_swap / v_permlane16_swap / row_ror:8 halve the number of
+//     live values at every step) leaves node (lane>>3)&7 of the chunk in each lane: 19 cross-lane
+//     operations per quantity for 8 nodes instead of 48;
+//   * only the nodes that matter are evaluated: Ke = (iterations of the previous call) + margin,
+//     grown when no stop index shows up among them;
+//   * the exchange has two stages: workgroup w publishes one 48-byte record per node (stage A);
+//     workgroup k < Ke gathers node k's 240 records, adds them in a fixed order and publishes the
+//     total (stage B); wave 0 of every workgroup reads the Ke totals (lane k = node k) and runs
+//     the recurrence.  Two ~2.5 us exchanges per round instead of K = 18-40 for the iteration.
+// Pads have e = 0 and drop out of every sum.  Per-thread and per-wave sums are fp32, cross-wave / cross-workgroup sums fp64 in a fixed
+// order, so every workgroup sees bit-identical totals and identical inputs + workspace state give
+// identical bits.  Protocol (sc1 stores / loads, self-tagged granules, parity buffers, tags from
+// the workspace base, wall-clock-bounded spins) as in rlvi_coop.h.
+#include <stdlib.h>
+
+#include "rlvi_traj.h"
+
+namespace rlvi {
+
+typedef unsigned int tb_vu4 __attribute__((ext_vector_type(4)));
+
+constexpr int TB_BLOCK = 512;        // 2 waves per SIMD: up to 256 VGPRs for the slice + 24 accumulators
+constexpr int TB_NW = TB_BLOCK / WAVE;
+constexpr int TB_G = 240;            // exchanging workgroups (+1 for the epoch-end reduction)
+constexpr int TB_CHUNK = 8;
+constexpr int TB_NV = 5;             // values of a record: {S, P, Q, D, min}
+constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
+
+struct TbShared {
+    float wp[TB_NW][TJ_MAXK][4];     // wave partials {S, P, Q, D} per node
+    float pmin[TB_NW];
+    double red[TB_PER][TB_NV];
+    TjOut out;
+};
+
+// v[q]: this lane's partial of node q of a chunk.  Returns, in lane l, the wave total of node
+// (l >> 3) & 7.  Fixed pairing order: deterministic.
+__device__ __forceinline__ float wave_reduce8(const float (&v)[TB_CHUNK]) {
+    float u[4], w[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {     // lanes < 32 keep node i, lanes >= 32 node i + 4
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        u[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {     // even rows keep node i (+4), odd rows node i + 2 (+4)
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[i]), __float_as_uint(u[i + 2]), false, false);
+        w[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const bool hi8 = (threadIdx.x & 8) != 0;
+    const float send = hi8 ? w[0] : w[1];
+    const float keep = hi8 ? w[1] : w[0];
+    const float x = keep + dpp_x<0x128>(send);            // row_ror:8
+    return group_allreduce<8>(x, FAdd());
+}
+
+// 48-byte record = six granules {tag32 | payload32}: {S, P, Q, D, min, -}; the first nq (4 or 5)
+// must carry `tag`.  Each 8-byte granule is self-tagged, so it does not matter that a 16-byte load
+// is only granule-atomic.
+__device__ __forceinline__ bool load_rec(gu64 *p, uint32_t tag, int nq, float (&val)[TB_NV]) {
+    tb_vu4 q0, q1, q2;
+    q2.x = 0u; q2.y = tag;
+    if (nq > 4)
+        asm volatile(
+            "global_load_dwordx4 %0, %3, off sc1\n\t"
+            "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(q0), "=&v"(q1), "=&v"(q2)
+            : "v"((unsigned long long)(uintptr_t)p)
+            : "memory");
+    else
+        asm volatile(
+            "global_load_dwordx4 %0, %2, off sc1\n\t"
+            "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(q0), "=&v"(q1)
+            : "v"((unsigned long long)(uintptr_t)p)
+            : "memory");
+    val[0] = __uint_as_float(q0.x); val[1] = __uint_as_float(q0.z);
+    val[2] = __uint_as_float(q1.x); val[3] = __uint_as_float(q1.z);
+    val[4] = __uint_as_float(q2.x);
+    return q0.y == tag && q0.w == tag && q1.y == tag && q1.w == tag && q2.y == tag;
+}
+
+__device__ __forceinline__ void store_rec(gu64 *p, uint32_t tag, int nq, const float (&val)[TB_NV]) {
+#pragma unroll
+    for (int q = 0; q < TB_NV; ++q)
+        if (q < nq)
+            __hip_atomic_store(p + q, ((unsigned long long)tag << 32) | __float_as_uint(val[q]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int E>
+__global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
+    float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
+    int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
+    float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg) {
+    int dbgi = 0;
+#define TB_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
+    TB_STAMP();
+    if ((int)blockIdx.x == TB_G) {   // epoch end: reduce + clear the M-step records (own CU)
+        double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF);
+        reduce_partials(part, MSTEP_MAX_BLOCKS, mstep_scale, mstep_out, true, TB_BLOCK);
+        return;
+    }
+    __shared__ TbShared sh;
+    if (threadIdx.x == 0) sh.out.dead = 0;
+    char *wsb = static_cast<char *>(ws);
+    WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
+    gu64 *bufA = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG3A_OFF));
+    gu64 *bufB = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG3B_OFF));
+    TrajState *state = reinterpret_cast<TrajState *>(wsb + WS_TRAJ_OFF);
+    uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    int xstep = 0;
+    bool dead = false;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = tid / WAVE;
+    const int b = (int)blockIdx.x;
+    const int64_t L = (N + TB_G - 1) / TB_G;
+    const int64_t lo = (int64_t)b * L;
+    const int64_t hi = lo + L < N ? lo + L : N;
+
+    // ---- warm-start state (read early: its latency hides behind the slice loads)
+    const bool warm = state->n == (long long)N && state->k == K;
+    const float shift = warm ? state->shift : 0.0f;     // guess of min(l); NLLs are >= 0
+    float rn_l = lane < K ? (warm ? state->nodes[lane] : 19.0f * exp2f(-(float)lane)) : 1.0f;
+    if (lane == 0) rn_l = (float)(0.95 / (1.0 - 0.95));
+    auto round8 = [K](int v) { v = (v + TB_CHUNK - 1) / TB_CHUNK * TB_CHUNK; return v < K ? v : K; };
+    int Ke = warm ? round8(state->it + 2) : K;            // evaluated nodes
+
+    // ---- slice -> registers: raw residuals, the caller's pi, local min
+    float l[E], ev[E], q0[E];
+    float mn = __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = lo + tid + (int64_t)j * TB_BLOCK;
+        const bool ok = i < hi;
+        l[j] = ok ? res[i] : __builtin_inff();
+        q0[j] = ok ? wts[i] : 0.0f;
+        mn = fminf(mn, l[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) ev[j] = expf(-(l[j] - shift));      // pads: exp(-inf) = 0
+    mn = group_allreduce<WAVE>(mn, FMin());
+    if (lane == 0) sh.pmin[wave] = mn;
+    TB_STAMP();   // slice loaded
+
+    const float invN = 1.0f / (float)N;
+    int it = K;
+    float r_fin = rn_l;
+    float gmin = 0.0f;
+    bool accepted = false;
+    const int max_rounds = 2 * K + 2;
+    for (int round = 0; round < max_rounds; ++round) {
+        // ---- per-node sums over this workgroup's slice, eight nodes at a time
+        float fprev[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) fprev[j] = q0[j];      // "node -1" = the caller's pi (D_0)
+        const int nchunks = (Ke + TB_CHUNK - 1) / TB_CHUNK;
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) {
+            float aI[TB_CHUNK], aP[TB_CHUNK], aQ[TB_CHUNK], aD[TB_CHUNK];
+#pragma unroll
+            for (int q = 0; q < TB_CHUNK; ++q) {
+                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn_l), c * TB_CHUNK + q));
+                // sample pairs in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
+                // samples per lane and instruction); only the reciprocal is per sample
+                f32x2_t pS = {0.0f, 0.0f}, pP = {0.0f, 0.0f}, pQ = {0.0f, 0.0f}, pD = {0.0f, 0.0f};
+                const f32x2_t r2 = {r, r}, one2 = {1.0f, 1.0f};
+#pragma unroll
+                for (int j = 0; j + 1 < E; j += 2) {
+                    const f32x2_t e2 = {ev[j], ev[j + 1]};
+                    const f32x2_t t = r2 * e2, t1 = t + one2;
+                    const f32x2_t inv = {__builtin_amdgcn_rcpf(t1.x), __builtin_amdgcn_rcpf(t1.y)};
+                    const f32x2_t f = t * inv;                                       // pi (:30)
+                    pS += f;
+                    const f32x2_t x = e2 * inv, y = x * inv;
+                    pP += y;                                                         // e/(1+re)^2
+                    pQ = __builtin_elementwise_fma(x, y, pQ);                        // e^2/(1+re)^3
+                    const f32x2_t d = f - (f32x2_t){fprev[j], fprev[j + 1]};          // pi_k - pi_{k-1}
+                    pD = __builtin_elementwise_fma(d, d, pD);
+                    fprev[j] = f.x; fprev[j + 1] = f.y;
+                }
+                float sI = pS.x + pS.y, sP = pP.x + pP.y, sQ = pQ.x + pQ.y, sD = pD.x + pD.y;
+                if constexpr ((E & 1) != 0) {
+                    constexpr int j = E - 1;
+                    const float t = r * ev[j];
+                    const float inv = __builtin_amdgcn_rcpf(1.0f + t);
+                    const float f = t * inv;
+                    sI += f;
+                    const float x = ev[j] * inv, y = x * inv;
+                    sP += y;
+                    sQ = fmaf(x, y, sQ);
+                    const float d = f - fprev[j];
+                    sD = fmaf(d, d, sD);
+                    fprev[j] = f;
+                }
+                aI[q] = sI; aP[q] = sP; aQ[q] = sQ; aD[q] = sD;
+            }
+            const float tI = wave_reduce8(aI);
+            const float tP = wave_reduce8(aP);
+            const float tQ = wave_reduce8(aQ);
+            const float tD = wave_reduce8(aD);
+            if ((lane & 7) == 0) {
+                float *dst = sh.wp[wave][c * TB_CHUNK + (lane >> 3)];
+                *reinterpret_cast<float4 *>(dst) = make_float4(tI, tP, tQ, tD);
+            }
+        }
+        TB_STAMP();   // sums done
+        __syncthreads();
+        gu64 *A = bufA + (size_t)(xstep & 1) * TJ_MAXK * MAX_COOP_WG * XCHG3_GRANULES;
+        gu64 *B = bufB + (size_t)(xstep & 1) * TJ_MAXK * XCHG3_GRANULES;
+        const int nq = round == 0 ? 5 : 4;
+        // ---- stage A: this workgroup's record of every evaluated node
+        if (wave == 0 && !dead && lane < Ke) {
+            double dI = 0.0, dP = 0.0, dQ = 0.0, dD = 0.0;
+#pragma unroll
+            for (int w = 0; w < TB_NW; ++w) {
+                const float4 v = *reinterpret_cast<const float4 *>(sh.wp[w][lane]);
+                dI += (double)v.x; dP += (double)v.y; dQ += (double)v.z; dD += (double)v.w;
+            }
+            float wmin = sh.pmin[0];
+#pragma unroll
+            for (int w = 1; w < TB_NW; ++w) wmin = fminf(wmin, sh.pmin[w]);
+            const float rec[TB_NV] = {(float)dI, (float)dP, (float)dQ, (float)dD, wmin};
+            store_rec(A + ((size_t)lane * MAX_COOP_WG + b) * XCHG3_GRANULES, tag, nq, rec);
+        }
+        TB_STAMP();   // stage A stored
+        // ---- stage B: workgroup k < Ke adds node k's records and publishes the total
+        if (b < Ke) {
+            if (wave < TB_PER && !dead) {
+                const int w = wave * WAVE + lane;
+                const bool mine = w < TB_G;
+                gu64 *p = A + ((size_t)b * MAX_COOP_WG + (mine ? w : 0)) * XCHG3_GRANULES;
+                const unsigned long long t0 = wall_clock64();
+                bool timeout = false;
+                float val[TB_NV] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                for (unsigned spin = 0;; ++spin) {
+                    const bool ok = load_rec(p, tag, nq, val) || !mine;
+                    if (__all(ok)) break;
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                        timeout = true;
+                        break;
+                    }
+                }
+                if (timeout) {
+                    if (lane == 0) { atomicOr(&hdr->status, RLVI_ST_TIMEOUT); sh.out.dead = 1; }
+                }
+                TB_STAMP();   // stage A gathered
+                const double vS = group_allreduce<WAVE>(mine ? (double)val[0] : 0.0, FAdd());
+                const double vP = group_allreduce<WAVE>(mine ? (double)val[1] : 0.0, FAdd());
+                const double vQ = group_allreduce<WAVE>(mine ? (double)val[2] : 0.0, FAdd());
+                const double vD = group_allreduce<WAVE>(mine ? (double)val[3] : 0.0, FAdd());
+                const float vM = group_allreduce<WAVE>((mine && nq > 4) ? val[4] : __builtin_inff(), FMin());
+                if (lane == 0) {
+                    sh.red[wave][0] = vS; sh.red[wave][1] = vP; sh.red[wave][2] = vQ;
+                    sh.red[wave][3] = vD; sh.red[wave][4] = (double)vM;
+                }
+            }
+            __syncthreads();
+            if (wave == 0 && !dead && sh.out.dead == 0) {
+                double tS = 0.0, tP = 0.0, tQ = 0.0, tD = 0.0, tM = (double)__builtin_inff();
+#pragma unroll
+                for (int w = 0; w < TB_PER; ++w) {            // fixed order
+                    tS += sh.red[w][0]; tP += sh.red[w][1]; tQ += sh.red[w][2]; tD += sh.red[w][3];
+                    tM = sh.red[w][4] < tM ? sh.red[w][4] : tM;
+                }
+                const float rec[TB_NV] = {(float)tS, (float)tP, (float)tQ, (float)tD, (float)tM};
+                if (lane == 0) store_rec(B + (size_t)b * XCHG3_GRANULES, tag, nq, rec);
+            }
+        }
+        TB_STAMP();   // published
+        // ---- wave 0: the Ke totals (lane k = node k), then the recurrence
+        if (wave == 0) {
+            dead = dead || sh.out.dead != 0;
+            float val[TB_NV] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (!dead) {
+                const bool mine = lane < Ke;
+                gu64 *p = B + (size_t)(mine ? lane : 0) * XCHG3_GRANULES;
+                const unsigned long long t0 = wall_clock64();
+                bool timeout = false;
+                for (unsigned spin = 0;; ++spin) {
+                    const bool ok = load_rec(p, tag, nq, val) || !mine;
+                    if (__all(ok)) break;
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                        timeout = true;
+                        break;
+                    }
+                }
+                if (timeout) {
+                    if (lane == 0) atomicOr(&hdr->status, RLVI_ST_TIMEOUT);
+                    dead = true;
+                }
+            }
+            TB_STAMP();   // totals in
+            const float gm = (lane < Ke && nq > 4) ? val[4] : __builtin_inff();
+            if (round == 0)
+                tj_chain<true>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2], (double)val[3],
+                               gm, dead,
+                               rn_l, shift, invN, tol, trace, true, xstep, dbg);
+            else
+                tj_chain<false>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2], (double)val[3],
+                               gm, dead,
+                                rn_l, shift, invN, tol, trace, true, xstep, dbg);
+        }
+        __syncthreads();
+        ++tag; ++xstep;
+        TB_STAMP();   // recurrence done
+        dead = sh.out.dead != 0;
+        it = sh.out.res_it;
+        r_fin = sh.out.res_rfin;
+        const float delta = sh.out.res_delta;
+        const bool found = sh.out.res_found != 0;
+        if (dbg != nullptr && b == 0 && tid == 0 && round < 24)
+            dbg[64 + round] = ((unsigned long long)((Ke << 8) | it) << 32) | __float_as_uint(delta);
+        rn_l = lane < K ? sh.out.nodes[lane] : 1.0f;
+        if (lane == 0) rn_l = (float)(0.95 / (1.0 - 0.95));
+        Ke = found ? round8(it + 2) : K;      // no stop index among the evaluated nodes: all of them
+        if (round == 0) {
+            // the true minimum is known now: residuals.sub_(min) (:27), e = exp(-residuals) (:28)
+            gmin = sh.out.res_min;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int64_t i = lo + tid + (int64_t)j * TB_BLOCK;
+                const float lv = l[j] - gmin;
+                if (i < hi) res[i] = lv;
+                ev[j] = expf(-lv);                          // pads stay 0
+            }
+        }
+        if (delta <= TJ_ACCEPT) { accepted = true; break; }
+        if (dead) break;
+    }
+    // every round makes at least one more node exact; anything else is a bug or a non-finite
+    // input: report it instead of returning silently wrong posteriors
+    if (!accepted && tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
+
+    // ---- weights = pi / max(pi); max is attained at e = 1 (the min-residual sample) (:38):
+    // same expression for f_max as per element and a true division, so that sample is exactly 1.0
+    const float tmax = r_fin * 1.0f;
+    const float pmax = tmax * __builtin_amdgcn_rcpf(1.0f + tmax);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = lo + tid + (int64_t)j * TB_BLOCK;
+        const float t = r_fin * ev[j];
+        if (i < hi) wts[i] = (t * __builtin_amdgcn_rcpf(1.0f + t)) / pmax;
+    }
+    TB_STAMP();   // final stores issued
+    if (dbg != nullptr && b == 0 && tid == 0) dbg[63] = (unsigned long long)dbgi;
+    if (b == 0 && tid < WAVE) {
+        if (tid == 0) {
+            if (out_iters != nullptr) *out_iters = it;
+            state->n = (long long)N;
+            state->k = K;
+            state->shift = gmin;
+            state->it = it;
+            __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < K) state->nodes[tid] = rn_l;
+    }
+}
+
+// Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if not applicable.
+// Measured crossover against the node-per-workgroup kernel (whole step, hipGraph): 24.1 vs 29.9 us
+// at N = 16 384, 34.1 vs 31.4 us at 32 768, 42.1 vs 36.1 us at 65 536, 60.7 vs 46.2 us at 131 072.
+int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
+                           int32_t *out_iters, float *trace, void *ws, hipStream_t st,
+                           float *mstep_out, double mstep_scale, int *rc) {
+    static const int mode = getenv("RLVI_ESTEP_TRAJB") ? atoi(getenv("RLVI_ESTEP_TRAJB")) : 1;
+    static const int64_t nmin = getenv("RLVI_ESTEP_TRAJB_NMIN") ? atoll(getenv("RLVI_ESTEP_TRAJB_NMIN")) : 24576;
+    if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin || N < TB_G) return 0;
+    const int64_t L = (N + TB_G - 1) / TB_G;
+    if (L > (int64_t)TB_BLOCK * 16) return 0;
+    const unsigned grid = (unsigned)TB_G + (mstep_out != nullptr ? 1u : 0u);
+    static const int debug = getenv("RLVI_TJ_DEBUG") ? atoi(getenv("RLVI_TJ_DEBUG")) : 0;
+    unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+#define RLVI_TB(E_)                                                                               \
+    hipLaunchKernelGGL((estep_trajb_kernel<E_>), dim3(grid), dim3(TB_BLOCK), 0, st, res, wts, N,  \
+                       tol, maxiter, out_iters, trace, ws, mstep_out, mstep_scale, dbg)
+    if (L <= (int64_t)TB_BLOCK * 2) RLVI_TB(2);
+    else if (L <= (int64_t)TB_BLOCK * 3) RLVI_TB(3);
+    else if (L <= (int64_t)TB_BLOCK * 4) RLVI_TB(4);
+    else if (L <= (int64_t)TB_BLOCK * 5) RLVI_TB(5);
+    else if (L <= (int64_t)TB_BLOCK * 6) RLVI_TB(6);
+    else if (L <= (int64_t)TB_BLOCK * 8) RLVI_TB(8);
+    else if (L <= (int64_t)TB_BLOCK * 12) RLVI_TB(12);
+    else RLVI_TB(16);
+#undef RLVI_TB
+    *rc = (int)hipGetLastError();
+    return 1;
+}
+
+}  // namespace rlvi

@@ -37,8 +37,15 @@ constexpr size_t WS_PART_OFF = WS_TRAJ_OFF + WS_TRAJ_BYTES;
 constexpr int MSTEP_MAX_BLOCKS = 1024;
 constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
 constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
+// third exchange region (large-N trajectory E-step, estep_trajb.hip), 48-byte records of six
+// self-tagged fp32 granules {S, P, Q, D, min, -}: stage A [2 parities][64 nodes][256 workgroups], stage B [2][64 nodes]
+constexpr int XCHG3_GRANULES = 6;
+constexpr size_t WS_XCHG3A_OFF = WS_PART_OFF + WS_PART_BYTES;
+constexpr size_t WS_XCHG3A_BYTES = 2ull * 64 * MAX_COOP_WG * XCHG3_GRANULES * 8;   // 1.5 MiB
+constexpr size_t WS_XCHG3B_OFF = WS_XCHG3A_OFF + WS_XCHG3A_BYTES;
+constexpr size_t WS_XCHG3B_BYTES = 2ull * 64 * XCHG3_GRANULES * 8;                 // 6 KiB
 // partial Gram matrices of the weighted-least-squares kernel: 8 workgroups x 64 x 64 doubles
-constexpr size_t WS_WLS_OFF = WS_PART_OFF + WS_PART_BYTES;
+constexpr size_t WS_WLS_OFF = WS_XCHG3B_OFF + WS_XCHG3B_BYTES;
 constexpr int WLS_MAX_WG = 8;
 constexpr size_t WS_WLS_BYTES = (size_t)WLS_MAX_WG * 64 * 64 * 8;               // 256 KiB
 constexpr size_t WS_SCRATCH_OFF = WS_WLS_OFF + WS_WLS_BYTES;

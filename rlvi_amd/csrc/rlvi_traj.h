@@ -1,0 +1,168 @@
+// Shared by the two trajectory E-step kernels (estep_traj.hip: one node per workgroup, medium N;
+// estep_trajb.hip: all nodes per workgroup over a small slice, large N): the warm-start state kept
+// in the workspace and the scalar recurrence one wave runs on the gathered per-node totals.
+#pragma once
+#include "rlvi_coop.h"
+
+namespace rlvi {
+
+constexpr int TJ_MAXK = 64;
+constexpr float TJ_ACCEPT = 1e-6f;
+
+struct TrajState {
+    long long n;
+    int k;
+    float shift;                 // min residual of the last call (guess of this call's shift)
+    float nodes[TJ_MAXK];
+    int it;                      // iterations of the last call (how many nodes are worth evaluating)
+};
+static_assert(sizeof(TrajState) <= WS_TRAJ_BYTES, "warm-start state must fit its workspace region");
+
+// what the recurrence leaves in LDS for the whole workgroup
+struct TjOut {
+    float nodes[TJ_MAXK];        // corrected trajectory of the latest round
+    int dead;
+    int res_it;
+    int res_found;               // a stop index was found among the evaluated nodes (or Ke == Ka)
+    float res_delta, res_rfin, res_min;
+};
+
+// ---------------------------------------------------------------------------------------
+// The recurrence of train_rlvi.py:30-37 on one wave.  Lane j holds node j: its guess rn_l and the
+// totals tS = S(rn), tP = dS/dr(rn), tQ = -1/2 d2S/dr2(rn) (0: first-order correction only),
+// tD = D(rn_j, rn_{j-1}) (D_0 against the caller's pi) over ALL
+// samples, for j < Ke (the evaluated nodes); Ka >= Ke nodes are kept in the state.  FIRST: the
+// sums were taken with e' = exp(-(l - shift)) and gmin (any lane's value is min-reduced here) is
+// the true minimum.  Results go to `out` (lane 0 / lanes < Ka); every lane must call.
+// ---------------------------------------------------------------------------------------
+template <bool FIRST>
+__device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, double tP, double tQ,
+                                         double tD,
+                                         float gmin, bool dead, float rn_l, float shift, float invN,
+                                         float tol, float *trace, bool want_nodes, int xstep,
+                                         unsigned long long *dbg) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool has = lane < Ke;
+    float scale = 1.0f;
+    if (FIRST) {
+        gmin = group_allreduce<WAVE>(gmin, FMin());
+        // the sums were taken with e' = exp(-(l - shift)) = e * exp(shift - min): in r-space the
+        // evaluated nodes are rn * exp(shift - min); not trustworthy if that factor is extreme
+        // or a sum overflowed
+        scale = expf(shift - gmin);
+    }
+    const float rn = rn_l * scale;
+    // (a node far below the trajectory may legitimately have S = 0 after fp32 underflow)
+    bool finite = has ? (tS == tS && tP == tP && tD == tD && tQ == tQ && tS < 1e300 && tP < 1e300 &&
+                             tD < 1e300 && tQ < 1e300)
+                      : true;
+    const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
+    if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+        if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tQ); }
+        if (lane == 0) { dbg[102] = __ballot(finite); dbg[103] = __float_as_uint(scale); }
+    }
+
+    // lane-parallel: a0 = mean(pi) at the node, b = d mean / dr, err = ||new - old||_2
+    const float a0_l = has ? (float)tS * invN : 0.0f;                                // (:35)
+    // (FIRST: tP is the derivative with respect to r' = r / scale)
+    const float b_l = has ? (float)(tP * (double)invN / (double)scale) : 0.0f;
+    const float c_l = has ? (float)(tQ * (double)invN / ((double)scale * (double)scale)) : 0.0f;
+    const float err_l = has ? sqrtf((float)tD) : __builtin_inff();                   // (:33)
+    const unsigned long long stopmask = __ballot(has && err_l < tol);                // (:36)
+    const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : Ke;
+    const bool found = stopmask != 0ull || Ke >= Ka;
+    const int steps = it_now + 2 < Ke ? it_now + 2 : Ke;      // a little lookahead
+    float r = (float)(0.95 / (1.0 - 0.95));
+    float rnew_l = rn;
+    float avg_l = 0.0f;
+    // serial chain; `step` is wave-uniform, so the per-node values come through v_readlane
+    // (SGPR lane select, no LDS):  avg = a0 + b d - c d^2, d = r - r',  r <- avg / (1 - avg).
+    // Fast form first (five dependent fp32 operations per step); its steps are then checked
+    // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
+    // that left it (cold or poor guesses) is redone in the damped form.
+    {
+#pragma unroll 1
+        for (int step = 0; step < steps; ++step) {
+            const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
+            const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
+            const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
+            const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_l), step));
+            if (lane == step) rnew_l = r;
+            const float dr = r - rns;
+            const float avg = fmaf(dr, fmaf(-cc, dr, bb), a0);
+            if (lane == step) avg_l = avg;
+            r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
+        }
+    }
+    const bool inside = !(has && lane < steps) ||
+                        (fabsf(rnew_l - rn) <= 0.5f * rn && avg_l > 0.0f && avg_l < 0.999999f);
+    if (!__all(inside)) {
+        r = (float)(0.95 / (1.0 - 0.95));
+#pragma unroll 1
+        for (int step = 0; step < steps; ++step) {
+            const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
+            const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
+            const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
+            const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_l), step));
+            if (lane == step) rnew_l = r;
+            // damped step: the linearisation is trusted within +-50% of the node (S is concave
+            // in r, so the extrapolated mean stays positive); mean(pi) < 1
+            const float h = 0.5f * rns;
+            const float d = fmaxf(fminf(r - rns, h), -h);
+            const float avg = fminf(fmaf(d, fmaf(-cc, d, bb), a0), 0.999999f);
+            if (lane == step) avg_l = avg;
+            r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-30f);              // (:31)
+        }
+    }
+    // nodes beyond the lookahead: a fresh geometric tail from the last corrected node
+    {
+        const float last = __shfl(rnew_l, steps - 1, WAVE);      // all lanes take part
+        if (lane < Ka && lane >= steps) rnew_l = last * exp2f(-(float)(lane - steps + 1));
+    }
+    float d_l = (has && lane < it_now) ? fabsf(rnew_l - rn) * __builtin_amdgcn_rcpf(rn) : 0.0f;
+    float delta_w = group_allreduce<WAVE>(d_l, FMax());
+    // Early accept: with nodes off by delta the corrected r are good to 0.25 delta^2, and the
+    // errors (evaluated AT the nodes) to about delta*(r_k + r_{k-1})/|r_k - r_{k-1}| relative.
+    // If every stop test up to `it` clears tol by 8x that margin, the stop index cannot change
+    // any more, and neither can pi: no verification round needed.  (Not when the caller asked
+    // for the error trace: that wants the errors themselves.)
+    const float rp_l = __shfl_up(rn, 1, WAVE);
+    if (delta_w > TJ_ACCEPT && delta_w <= 1e-3f && trace == nullptr) {
+        float u = 0.0f;
+        if (has && lane < it_now && lane > 0) {
+            const float gap = fabsf(rn - rp_l);
+            u = 8.0f * delta_w * (rn + rp_l) * __builtin_amdgcn_rcpf(fmaxf(gap, 1e-30f));
+        }
+        if (lane == 0) u = 128.0f * delta_w;            // D_0 is taken against the caller's pi
+        const bool unsafe = has && lane < it_now && fabsf(err_l - tol) <= u * err_l;
+        if (__ballot(unsafe) == 0ull) delta_w = 0.0f;
+    }
+    if (dbg != nullptr && blockIdx.x == 0 && xstep < 4)
+        dbg[400 + xstep * 64 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
+    if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+        dbg[130 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
+        if (lane == 0) { dbg[128] = round_ok; dbg[129] = ((unsigned long long)it_now << 32) | __float_as_uint(delta_w); }
+    }
+    // guesses stay where sums in fp32 cannot underflow; an invalid round restarts from the
+    // geometric cold guess instead of re-evaluating the nodes that broke it; a round that did not
+    // reach the stop index (too few nodes evaluated) is never accepted
+    rnew_l = fminf(fmaxf(rnew_l, 1e-30f), 1e30f);
+    if (!found) delta_w = __builtin_inff();
+    if (!round_ok) { delta_w = __builtin_inff(); rnew_l = 19.0f * exp2f(-(float)lane); }
+    if (lane < Ka && want_nodes) out.nodes[lane] = rnew_l;
+    if (trace != nullptr && blockIdx.x == 0 && lane < it_now && round_ok && found) {
+        trace[2 * lane] = err_l;
+        trace[2 * lane + 1] = avg_l;
+    }
+    const float rfin_w = __shfl(rnew_l, it_now - 1, WAVE);   // all lanes take part
+    if (lane == 0) {
+        out.res_it = it_now;
+        out.res_found = (found && round_ok) ? 1 : 0;
+        out.res_delta = delta_w;
+        out.res_rfin = rfin_w;
+        if (FIRST) out.res_min = gmin;
+        out.dead = dead ? 1 : 0;
+    }
+}
+
+}  // namespace rlvi

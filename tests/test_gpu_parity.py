@@ -289,9 +289,11 @@ def test_threshold_vs_oracle_sizes(N, gpu, oracle):
     assert int(kept) == int(m_ref.sum())
 
 
-@pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 50000, 65536, 75750, 200000, 600000])
+@pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 24575, 24576, 50000, 65536, 75750, 200000,
+                               200001, 262144, 524288, 600000, 1000003, 1966080, 1966081])
 def test_estep_vs_oracle_sizes(N, gpu, oracle):
-    """Iterative (N < 4096) and trajectory (N >= 4096, register and streaming slices) solvers.
+    """Iterative (N < 4096, N > 1 966 080), node-per-workgroup trajectory (4096..24 575) and
+    slice-per-workgroup trajectory (24 576..1 966 080) solvers.
 
     Determinism: from the same workspace state two runs are bit-identical (fixed reduction
     order -- this is also the race detector).  The trajectory solver warm-starts from the last
@@ -324,12 +326,12 @@ def test_estep_vs_oracle_sizes(N, gpu, oracle):
     assert outs[0][1].max() == np.float32(1.0)           # weights.div_(weights.max()) (:38)
 
 
-def test_estep_trajectory_cold_warm_and_poor_guess(gpu, oracle):
+@pytest.mark.parametrize("N", [12000, 30000, 300000])
+def test_estep_trajectory_cold_warm_and_poor_guess(N, gpu, oracle):
     """The trajectory solver must not depend on the quality of its starting guess: cold start,
     warm start from the same data, and warm start from a very different vector of the same
     length (a poor guess: more Newton rounds) all give the oracle's iteration count and pi."""
     torch, ops, dev = gpu
-    N = 30000
     ws = ops.Workspace(dev, N, 0)
     seq = [("bimodal", 1), ("bimodal", 1), ("heavy", 2), ("equal", 3), ("exp", 4), ("zeros10", 5),
            ("bimodal", 6)]
