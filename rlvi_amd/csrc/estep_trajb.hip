@@ -29,13 +29,15 @@ namespace rlvi {
 
 typedef unsigned int tb_vu4 __attribute__((ext_vector_type(4)));
 
-constexpr int TB_BLOCK = 512;        // 2 waves per SIMD: up to 256 VGPRs for the slice + 24 accumulators
-constexpr int TB_NW = TB_BLOCK / WAVE;
+// Workgroup size: 256 threads = one wave per SIMD (the per-wave butterflies are a fixed cost per
+// wave and chunk, so fewer, fatter waves win as long as the slice fits the registers); the main loop
+// has no memory operations to hide and eight independent nodes of instruction-level parallelism.
 constexpr int TB_G = 240;            // exchanging workgroups (+1 for the epoch-end reduction)
 constexpr int TB_CHUNK = 8;
 constexpr int TB_NV = 5;             // values of a record: {S, P, Q, D, min}
 constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
 
+template <int TB_NW>
 struct TbShared {
     float wp[TB_NW][TJ_MAXK][4];     // wave partials {S, P, Q, D} per node
     float pmin[TB_NW];
@@ -101,7 +103,7 @@ __device__ __forceinline__ void store_rec(gu64 *p, uint32_t tag, int nq, const f
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int E>
+template <int E, int TB_BLOCK>
 __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
@@ -114,7 +116,9 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         reduce_partials(part, MSTEP_MAX_BLOCKS, mstep_scale, mstep_out, true, TB_BLOCK);
         return;
     }
-    __shared__ TbShared sh;
+    constexpr int TB_NW = TB_BLOCK / WAVE;
+    static_assert(TB_NW >= TB_PER, "the stage-A gather needs four waves");
+    __shared__ TbShared<TB_NW> sh;
     if (threadIdx.x == 0) sh.out.dead = 0;
     char *wsb = static_cast<char *>(ws);
     WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
@@ -384,21 +388,36 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     static const int64_t nmin = getenv("RLVI_ESTEP_TRAJB_NMIN") ? atoll(getenv("RLVI_ESTEP_TRAJB_NMIN")) : 24576;
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin || N < TB_G) return 0;
     const int64_t L = (N + TB_G - 1) / TB_G;
-    if (L > (int64_t)TB_BLOCK * 16) return 0;
+    if (L > 8192) return 0;
     const unsigned grid = (unsigned)TB_G + (mstep_out != nullptr ? 1u : 0u);
     static const int debug = getenv("RLVI_TJ_DEBUG") ? atoi(getenv("RLVI_TJ_DEBUG")) : 0;
+    // 256 threads measured 2-3 us per call ahead up to N = 262 144, level at 524 288, 1 us behind
+    // from 1e6 on (whole step / eager call, hipGraph): 512 threads only for slices beyond 4096
+    static const int blk = getenv("RLVI_TB_BLOCK") ? atoi(getenv("RLVI_TB_BLOCK")) : 0;
     unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
-#define RLVI_TB(E_)                                                                               \
-    hipLaunchKernelGGL((estep_trajb_kernel<E_>), dim3(grid), dim3(TB_BLOCK), 0, st, res, wts, N,  \
+#define RLVI_TB(E_, B_)                                                                           \
+    hipLaunchKernelGGL((estep_trajb_kernel<E_, B_>), dim3(grid), dim3(B_), 0, st, res, wts, N,    \
                        tol, maxiter, out_iters, trace, ws, mstep_out, mstep_scale, dbg)
-    if (L <= (int64_t)TB_BLOCK * 2) RLVI_TB(2);
-    else if (L <= (int64_t)TB_BLOCK * 3) RLVI_TB(3);
-    else if (L <= (int64_t)TB_BLOCK * 4) RLVI_TB(4);
-    else if (L <= (int64_t)TB_BLOCK * 5) RLVI_TB(5);
-    else if (L <= (int64_t)TB_BLOCK * 6) RLVI_TB(6);
-    else if (L <= (int64_t)TB_BLOCK * 8) RLVI_TB(8);
-    else if (L <= (int64_t)TB_BLOCK * 12) RLVI_TB(12);
-    else RLVI_TB(16);
+    if (blk == 512 || (blk == 0 && L > 256 * 16)) {
+        if (L <= 512 * 2) RLVI_TB(2, 512);
+        else if (L <= 512 * 4) RLVI_TB(4, 512);
+        else if (L <= 512 * 6) RLVI_TB(6, 512);
+        else if (L <= 512 * 8) RLVI_TB(8, 512);
+        else if (L <= 512 * 12) RLVI_TB(12, 512);
+        else RLVI_TB(16, 512);
+    } else {
+        if (L <= 256 * 1) RLVI_TB(1, 256);
+        else if (L <= 256 * 2) RLVI_TB(2, 256);
+        else if (L <= 256 * 3) RLVI_TB(3, 256);
+        else if (L <= 256 * 4) RLVI_TB(4, 256);
+        else if (L <= 256 * 6) RLVI_TB(6, 256);
+        else if (L <= 256 * 8) RLVI_TB(8, 256);
+        else if (L <= 256 * 10) RLVI_TB(10, 256);
+        else if (L <= 256 * 12) RLVI_TB(12, 256);
+        else if (L <= 256 * 16) RLVI_TB(16, 256);
+        else if (L <= 256 * 24) RLVI_TB(24, 256);
+        else RLVI_TB(32, 256);
+    }
 #undef RLVI_TB
     *rc = (int)hipGetLastError();
     return 1;

@@ -64,9 +64,11 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
 
     // lane-parallel: a0 = mean(pi) at the node, b = d mean / dr, err = ||new - old||_2
     const float a0_l = has ? (float)tS * invN : 0.0f;                                // (:35)
-    // (FIRST: tP is the derivative with respect to r' = r / scale)
-    const float b_l = has ? (float)(tP * (double)invN / (double)scale) : 0.0f;
-    const float c_l = has ? (float)(tQ * (double)invN / ((double)scale * (double)scale)) : 0.0f;
+    // (FIRST: tP, tQ are derivatives with respect to r' = r / scale; b and c only steer the
+    //  correction, fp32 is plenty)
+    const float iscale = FIRST ? __builtin_amdgcn_rcpf(scale) : 1.0f;
+    const float b_l = has ? (float)tP * invN * iscale : 0.0f;
+    const float c_l = has ? (float)tQ * invN * iscale * iscale : 0.0f;
     const float err_l = has ? sqrtf((float)tD) : __builtin_inff();                   // (:33)
     const unsigned long long stopmask = __ballot(has && err_l < tol);                // (:36)
     const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : Ke;
