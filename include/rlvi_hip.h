@@ -132,6 +132,17 @@ int rlvi_truncate_f32(float *weights, int64_t N, const float *thr, uint8_t *mask
                       void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Small-loss selection (the baselines that share the "per-sample CE -> select -> mean" shape,
+ * SURVEY 8(f)-4).  Replaces  ind_sorted = np.argsort(loss.cpu()); ind_update = ind_sorted[:k]
+ * (train_usdnl.py:18-24, train_coteaching.py:18-30): mask_w[i] = 1.0f for the k smallest of the n
+ * losses, else 0.0f; equal losses are taken in index order (a stable argsort), NaN orders last.
+ * The selected rows are then weighted through rlvi_mstep_fwd_bwd_* with weights = mask_w,
+ * idx = NULL and inv_scale = 1/k (usdnl) or 1/k^2 (co-teaching's mean followed by /num_remember,
+ * train_coteaching.py:32-35).  k <= 0 selects nothing, k >= n everything.
+ * ------------------------------------------------------------------------------------- */
+int rlvi_select_smallest_f32(const float *loss, int64_t n, int64_t k, float *mask_w, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * In-batch fused E+M (online order, online-learning/main.py:296-299 applied to a logit block):
  * per-sample NLL -> E-step on THIS batch (deep variant, pi_in only feeds the first error)
  * -> weighted loss and gradient with the NEW pi.  Composition of a1, a7, a4, a5.

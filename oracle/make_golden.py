@@ -16,6 +16,7 @@ Golden sets:
   G5 standard     update_weights, linear/logistic  standard-learning/rlvi.py
   G6 online       update_weights_rlvi, CE          online-learning/main.py:45-58,:84-85
   G7 estimators   mean, pca, covariance            standard-learning/rlvi.py:23-65,:111-144
+  G8 small-loss   usdnl.loss_fn, loss_coteaching   train_usdnl.py:16-27, train_coteaching.py:17-35
 """
 import argparse
 import os
@@ -357,7 +358,41 @@ def gen_g7(ref):
     save("g7_estimators", **out)
 
 
-GROUPS = {"g7": gen_g7, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
+def gen_g8(ref):
+    """Small-loss selection baselines: loss values and logits gradients."""
+    import torch
+    ref_deep(ref)
+    usdnl = sys.modules["methods.train_usdnl"]
+    cot = sys.modules["methods.train_coteaching"]
+    out = {}
+    keys = []
+    for (B, C, fr) in ((64, 10, 0.2), (200, 100, 0.45), (1000, 14, 0.0), (37, 10, 0.9)):
+        seed = 800 + B + C
+        d1 = synth.mstep_inputs(B, C, N=B, seed=seed, zero_frac=0.0)
+        d2 = synth.mstep_inputs(B, C, N=B, seed=seed + 1, zero_frac=0.0)
+        labels = torch.from_numpy(d1["labels"])
+        key = f"B{B}_C{C}"
+        keys.append(key)
+        out[key + "/B"], out[key + "/C"] = np.array(B), np.array(C)
+        out[key + "/seed"], out[key + "/forget_rate"] = np.array(seed), np.array(fr)
+        z = torch.from_numpy(d1["logits"].copy()).requires_grad_(True)
+        loss = usdnl.loss_fn(z, labels, fr)
+        loss.backward()
+        out[key + "/usdnl_loss"] = np.array(np.float32(loss.item()))
+        out[key + "/usdnl_grad"] = z.grad.numpy()
+        z1 = torch.from_numpy(d1["logits"].copy()).requires_grad_(True)
+        z2 = torch.from_numpy(d2["logits"].copy()).requires_grad_(True)
+        l1, l2 = cot.loss_coteaching(z1, z2, labels, fr, None)
+        (l1 + l2).backward()
+        out[key + "/cot_loss1"] = np.array(np.float32(l1.item()))
+        out[key + "/cot_loss2"] = np.array(np.float32(l2.item()))
+        out[key + "/cot_grad1"] = z1.grad.numpy()
+        out[key + "/cot_grad2"] = z2.grad.numpy()
+    out["cases"] = np.array(keys)
+    save("g8_small_loss", **out)
+
+
+GROUPS = {"g7": gen_g7, "g8": gen_g8, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

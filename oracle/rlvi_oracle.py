@@ -131,6 +131,42 @@ def mstep(logits, labels, idx, weights, residuals, scale_div=None, want_grad=Tru
                 grad=grad, loss_rows=rows)
 
 
+def select_smallest(losses, k):
+    """0/1 weights of np.argsort(loss)[:k] (train_usdnl.py:18-24, train_coteaching.py:18-30).
+    Stable order: equal losses are taken by index (numpy's default sort leaves that open)."""
+    mask = np.zeros(len(losses), np.float32)
+    if k > 0:
+        mask[np.argsort(losses, kind="stable")[:k]] = 1.0
+    return mask
+
+
+def _selected_ce(logits, labels, mask, div):
+    B = logits.shape[0]
+    r = mstep(logits, labels, np.arange(B, dtype=np.int64), mask, np.zeros(B, np.float32),
+              scale_div=div)
+    return r["loss"], r["grad"]
+
+
+def usdnl_loss(logits, labels, forget_rate):
+    """train_usdnl.loss_fn (:16-27): mean CE over the num_remember smallest losses -> (loss, grad)."""
+    B = logits.shape[0]
+    k = int((1 - forget_rate) * B)
+    rows, _ = nll_rows(logits, labels)
+    return _selected_ce(logits, labels, select_smallest(rows, k), k)
+
+
+def coteaching_loss(y1, y2, t, forget_rate):
+    """train_coteaching.loss_coteaching (:17-35): each model is averaged over the rows the OTHER
+    one finds easy, and (as the reference does) divided by num_remember once more."""
+    B = y1.shape[0]
+    k = int((1 - forget_rate) * B)
+    r1, _ = nll_rows(y1, t)
+    r2, _ = nll_rows(y2, t)
+    l1, g1 = _selected_ce(y1, t, select_smallest(r2, k), k * k)
+    l2, g2 = _selected_ce(y2, t, select_smallest(r1, k), k * k)
+    return l1, l2, g1, g2
+
+
 def update_sample_weights(residuals, weights, tol=1e-3, maxiter=40, trace=False):
     """a7, in place on both arrays (train_rlvi.py:14-38).  Returns iterations
     (and the per-iteration error / mean-pi traces when trace=True)."""

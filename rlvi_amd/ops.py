@@ -329,6 +329,50 @@ class _WeightedCE(torch.autograd.Function):
         return grad * g_loss.to(grad.dtype), None, None, None, None, None
 
 
+def select_smallest(losses, k, out=None):
+    """mask[i] = 1.0 for the k smallest losses, else 0.0 -- np.argsort(loss)[:k] of the small-loss
+    baselines (train_usdnl.py:18-24, train_coteaching.py:18-30) as a weight vector; equal losses in
+    index order.  One launch, no host round trip."""
+    L = _lib.load()
+    _require_gpu(losses)
+    if losses.dtype != torch.float32 or not losses.is_contiguous() or losses.dim() != 1:
+        raise ValueError("losses must be a contiguous 1-D fp32 tensor")
+    if out is None:
+        out = torch.empty_like(losses)
+    _lib.check(L.rlvi_select_smallest_f32(_ptr(losses), losses.shape[0], int(k), _ptr(out),
+                                          _stream_ptr()), "rlvi_select_smallest_f32")
+    return out
+
+
+def per_sample_ce(logits, labels, ws=None):
+    """F.cross_entropy(logits, labels, reduction='none') by the streaming kernel (forward only)."""
+    B = logits.shape[0]
+    rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    ones = torch.ones(B, dtype=torch.float32, device=logits.device)
+    mstep_fwd_bwd(logits, labels, None, ones, rows, want_grad=False, ws=ws)
+    return rows
+
+
+class _SelectedCE(torch.autograd.Function):
+    """loss = inv_scale * sum_i mask_i * CE(logits_i, y_i) for a fixed 0/1 mask; backward hands out
+    the gradient the fused kernel wrote (zero rows for unselected samples)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, mask, inv_scale):
+        out, grad = mstep_fwd_bwd(logits.detach(), labels, None, mask, None, inv_scale)
+        ctx.save_for_backward(grad)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss.to(grad.dtype), None, None, None
+
+
+def selected_cross_entropy(logits, labels, mask, inv_scale):
+    return _SelectedCE.apply(logits, labels, mask, inv_scale)
+
+
 def weighted_cross_entropy(logits, labels, idx, weights, residuals, inv_scale=None):
     """Autograd entry: returns (loss 0-dim tensor, out[4])."""
     return _WeightedCE.apply(logits, labels, idx, weights, residuals, inv_scale)
