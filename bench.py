@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)")
+    ap.add_argument("--dist-graph", default="auto", choices=["auto", "off"],
+                    help="world > 1: capture the RCCL all-gather in the hipGraph too (auto: try, and "
+                         "fall back to eager launches on every rank if any rank cannot)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="debug: run the residual exchange (and its process group) at world size 1")
     ap.add_argument("--profile-only", action="store_true",
                     help="warmup + timed steps only (for rocprofv3 runs)")
     return ap.parse_args()
@@ -91,12 +96,30 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.same_device:
         local = 0
-    if world > 1:
+    use_dist = world > 1 or a.force_collective
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(a.backend)
+        # RCCL prints a version banner on stdout when the communicator is created; stdout is
+        # reserved for the one JSON line, so fd 1 points at stderr until the first collective is done
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                dist.barrier(device_ids=[local])
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(a.backend)
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
     if a.gpus != world and rank == 0:
@@ -116,8 +139,8 @@ def main():
         r = i % ROTATE
         ops.mstep_fwd_bwd(logits[r], labels, idx_local, weights, residuals, inv_scale=inv_scale,
                           grad=grads[r], ws=ws, accumulate=True)
-        if world > 1:
-            rdist.exchange_residuals_owned(residuals, rank * B, (rank + 1) * B)
+        if use_dist:
+            rdist.exchange_residuals_owned(residuals, rank * B, (rank + 1) * B, force=a.force_collective)
         ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
 
     def mstep_only(i, ws):
@@ -129,7 +152,7 @@ def main():
         ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,11 +194,25 @@ def main():
             torch.cuda.synchronize()
             graph = None
             if use_graph:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    for i in range(K):
-                        fn(W + i, ws)
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        for i in range(K):
+                            fn(W + i, ws)
+                except Exception as e:              # only the collective can refuse a capture
+                    if not use_dist:
+                        raise
+                    print(f"# rank {rank}: graph capture refused ({type(e).__name__}: {e}); eager",
+                          file=sys.stderr)
+                    graph = None
                 torch.cuda.synchronize()
+                if use_dist:                        # every rank takes the same road
+                    okf = torch.tensor([1 if graph is not None else 0], dtype=torch.int32,
+                                       device=dev if a.backend == "nccl" else "cpu")
+                    dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                    if int(okf.item()) == 0:
+                        graph = None
+                launch_mode[fn.__name__] = "hipGraph" if graph is not None else "eager"
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             sync_all()
             e0.record(side)
@@ -188,13 +225,15 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
         sync_all()
-        if world > 1:
+        if use_dist:
             t = torch.tensor([ms], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t.item())
         return ms
 
-    use_graph = (not a.no_graph) and world == 1     # RCCL calls stay eager
+    # world > 1: the RCCL all-gather is captured too when RCCL allows it (--dist-graph auto)
+    use_graph = (not a.no_graph) and (not use_dist or a.dist_graph == "auto")
+    launch_mode = {}
     K, W = a.steps, a.warmup
     ms_total = timed(step, K, W, use_graph)
     ms_step = ms_total / K
@@ -209,7 +248,7 @@ def main():
                                "M-step (lagged pi) + E-step every step, HBM-cold rotation of "
                                f"{ROTATE} buffer pairs",
                    "rows_per_gpu": B, "classes": C, "n_samples": N,
-                   "launch": "hipGraph" if use_graph else "eager"},
+                   "launch": launch_mode.get("step", "eager")},
     }
     if a.profile_only:
         if rank == 0:
@@ -287,7 +326,7 @@ def main():
         }
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -42,10 +42,11 @@ def global_batch(b_local, group=None):
     return int(t.item())
 
 
-def exchange_residuals_owned(residuals, start, stop, group=None):
+def exchange_residuals_owned(residuals, start, stop, group=None, force=False):
     """Every rank owns the contiguous slice [start, stop) of equal length: one
-    all_gather_into_tensor straight into the replicated vector (N = world * (stop-start))."""
-    if not is_dist():
+    all_gather_into_tensor straight into the replicated vector (N = world * (stop-start)).
+    force: issue the collective even in a one-rank group (rehearsing graph capture)."""
+    if not (is_dist() or (force and dist.is_initialized())):
         return
     world = dist.get_world_size(group)
     n = stop - start
