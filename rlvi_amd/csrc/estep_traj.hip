@@ -322,7 +322,9 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
     // f_max is evaluated with the very expression used per element and the normalisation is a
     // true division, so the min-residual sample (e = 1) comes out as exactly 1.0, as div_(max) does
     const float tmax = r_fin * 1.0f;
-    const float pmax = tmax * __builtin_amdgcn_rcpf(1.0f + tmax);
+    // (a solve that did not converge -- a non-finite residual -- poisons every weight, as the
+    //  reference's min / mean over a vector with a NaN does)
+    const float pmax = accepted ? tmax * __builtin_amdgcn_rcpf(1.0f + tmax) : __builtin_nanf("");
     // workgroup (k, s) writes the elements of slice s whose position is congruent to k mod K
     // (position mod K advances by 1024 mod K per step: no per-element division)
     {

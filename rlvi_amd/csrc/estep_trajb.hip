@@ -355,7 +355,9 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     // ---- weights = pi / max(pi); max is attained at e = 1 (the min-residual sample) (:38):
     // same expression for f_max as per element and a true division, so that sample is exactly 1.0
     const float tmax = r_fin * 1.0f;
-    const float pmax = tmax * __builtin_amdgcn_rcpf(1.0f + tmax);
+    // (a solve that did not converge -- a non-finite residual -- poisons every weight, as the
+    //  reference's min / mean over a vector with a NaN does)
+    const float pmax = accepted ? tmax * __builtin_amdgcn_rcpf(1.0f + tmax) : __builtin_nanf("");
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int64_t i = lo + tid + (int64_t)j * TB_BLOCK;

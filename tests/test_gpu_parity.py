@@ -411,6 +411,45 @@ def test_estep_cooperative_under_concurrent_load(gpu, oracle):
         assert rel <= REL and small <= 1e-7
 
 
+@pytest.mark.parametrize("N", [300, 5000, 30000])
+def test_estep_non_finite_and_extreme_inputs(N, gpu, oracle):
+    """+inf / 1e30 residuals (pi = 0), negative residuals, an all-equal vector and a 1e-7 spread
+    behave as in the reference; a NaN residual poisons every weight (as torch.min / mean do) and
+    raises the sticky RLVI_ST_NOCONV flag on the trajectory solvers."""
+    torch, ops, dev = gpu
+    for case in ("inf_some", "huge", "neg", "all_equal_big", "tiny_spread", "nan_one"):
+        r = synth.residual_vector("bimodal", N, seed=3)
+        if case == "inf_some":
+            r[::7] = np.inf
+        elif case == "huge":
+            r[::5] = 1e30
+        elif case == "neg":
+            r = r - np.float32(50.0)
+        elif case == "all_equal_big":
+            r[:] = 1e20
+        elif case == "tiny_spread":
+            r = (1.0 + 1e-7 * np.arange(N)).astype(np.float32)
+        else:
+            r[11] = np.nan
+        ws = ops.Workspace(dev, N, 0)
+        rt, wt = torch.from_numpy(r.copy()).to(dev), torch.ones(N, device=dev)
+        it = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=it, ws=ws)
+        torch.cuda.synchronize()
+        rr, ww = r.copy(), np.ones(N, np.float32)
+        with np.errstate(all="ignore"):
+            ito = oracle.update_sample_weights(rr, ww)
+        w = wt.cpu().numpy()
+        assert int(it) == ito, case
+        if case == "nan_one":
+            assert np.isnan(w).all() and np.isnan(ww).all()
+            assert ws.status() in (0, 4)          # (the iterative kernel has no convergence flag)
+        else:
+            assert ws.status() == 0, case
+            rel, small = rel_pi(w, ww)
+            assert rel <= REL and small <= 1e-7, case
+
+
 def test_estep_bench_size_properties(gpu):
     """Size-independent E-step properties at the BASELINE size (65 536) on the HIP path: max pi is
     exactly 1, pi is non-increasing in the loss, the min shift is exact, the caller's weights do
