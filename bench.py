@@ -49,9 +49,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)")
-    ap.add_argument("--dist-graph", default="auto", choices=["auto", "off"],
-                    help="world > 1: capture the RCCL all-gather in the hipGraph too (auto: try, and "
-                         "fall back to eager launches on every rank if any rank cannot)")
+    ap.add_argument("--dist-graph", default="off", choices=["auto", "off"],
+                    help="world > 1: 'auto' captures the RCCL all-gather in the hipGraph too (and falls "
+                         "back to eager launches on every rank if any rank cannot).  Default off: the "
+                         "eager loop costs ~45 us of host time per step, about what the GPU needs at "
+                         "2+ ranks, and an eager RCCL call cannot hang a replay")
     ap.add_argument("--force-collective", action="store_true",
                     help="debug: run the residual exchange (and its process group) at world size 1")
     ap.add_argument("--profile-only", action="store_true",
