@@ -105,3 +105,22 @@ def test_plugin_interface_matches_reference_names():
     sig = inspect.signature(m.false_negative_criterion)
     assert list(sig.parameters) == ["weights", "alpha"] and sig.parameters["alpha"].default == 0.05
     assert methods.train_rlvi is mod_fn
+
+
+def test_small_loss_baseline_interfaces_match_reference_names():
+    """train_usdnl.py:16,30 and train_coteaching.py:17,39: same names, positional order, __all__."""
+    import inspect
+    import sys
+    from rlvi_amd import methods
+    import rlvi_amd.methods.train_coteaching  # noqa: F401
+    import rlvi_amd.methods.train_usdnl  # noqa: F401
+    u = sys.modules["rlvi_amd.methods.train_usdnl"]
+    c = sys.modules["rlvi_amd.methods.train_coteaching"]
+    assert u.__all__ == ['train_usdnl'] and c.__all__ == ['train_coteaching']
+    assert list(inspect.signature(u.loss_fn).parameters) == ["logits", "labels", "forget_rate"]
+    assert list(inspect.signature(u.train_usdnl).parameters) == [
+        "train_loader", "epoch", "model", "optimizer", "rate_schedule"]
+    assert list(inspect.signature(c.loss_coteaching).parameters) == ["y_1", "y_2", "t", "forget_rate", "ind"]
+    assert list(inspect.signature(c.train_coteaching).parameters) == [
+        "train_loader", "epoch", "model1", "optimizer1", "model2", "optimizer2", "rate_schedule"]
+    assert methods.train_usdnl is u.train_usdnl and methods.train_coteaching is c.train_coteaching
