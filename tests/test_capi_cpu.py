@@ -124,3 +124,21 @@ def test_small_loss_baseline_interfaces_match_reference_names():
     assert list(inspect.signature(c.train_coteaching).parameters) == [
         "train_loader", "epoch", "model1", "optimizer1", "model2", "optimizer2", "rate_schedule"]
     assert methods.train_usdnl is u.train_usdnl and methods.train_coteaching is c.train_coteaching
+
+
+def _build_capi_example(tmp_path):
+    import shutil
+    import subprocess
+    from rlvi_amd import _build
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "capi_smoke")
+    libdir = os.path.dirname(_build.LIB)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-I" + os.path.join(_build.ROOT, "include"),
+                           os.path.join(_build.ROOT, "examples", "capi_smoke.cpp"), "-L" + libdir,
+                           "-lrlvi_gfx950", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_cpp_host_program_links_against_the_c_abi(lib, tmp_path):
+    """examples/capi_smoke.cpp (no Python, no torch) compiles and links against the header + .so."""
+    assert os.path.exists(_build_capi_example(tmp_path))

@@ -815,3 +815,14 @@ def test_small_loss_baselines_train_loops(gpu):
         test_acc = driver.evaluate(driver.IndexedLoader(xt, yt, 512, shuffle=False), m1, dev)
         assert test_acc > 85.0, (which, test_acc)
     assert ops.workspace(dev).status() == 0
+
+
+def test_cpp_host_program_over_the_c_abi(gpu, tmp_path):
+    """The C ABI without Python or torch: examples/capi_smoke.cpp runs an M-step, the epoch end, the
+    threshold and a small-loss selection and checks them against host arithmetic."""
+    import subprocess
+    from test_capi_cpu import _build_capi_example
+    exe = _build_capi_example(tmp_path)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "-> ok" in p.stdout
