@@ -162,7 +162,7 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
             }
         }
         TJ_RS(4);
-        tj_chain<FIRST>(sh.out, K, K, tS, tP, 0.0, tD, gmin, dead, rn_l, shift, invN, tol, trace,
+        tj_chain<FIRST, false>(sh.out, K, K, tS, tP, 0.0, tD, gmin, dead, rn_l, shift, invN, tol, trace,
                         want_nodes, xstep, dbg);
         TJ_RS(6);
     }

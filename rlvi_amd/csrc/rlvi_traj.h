@@ -8,6 +8,9 @@ namespace rlvi {
 
 constexpr int TJ_MAXK = 64;
 constexpr float TJ_ACCEPT = 1e-6f;
+#ifndef RLVI_TJ_TRUST
+#define RLVI_TJ_TRUST 0.25f
+#endif
 
 struct TrajState {
     long long n;
@@ -27,6 +30,24 @@ struct TjOut {
     float res_delta, res_rfin, res_min;
 };
 
+// Ascending bitonic sort of one key per lane over the 64 lanes of a wave; `src` (initialised to the
+// lane id by the caller) ends up as the lane the key of each sorted position came from.  Ties are
+// ordered by `src`, so the compare-exchange is a strict total order and both lanes of a pair agree.
+__device__ __forceinline__ void wave_sort_keys(float &key, int &src) {
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int k = 2; k <= WAVE; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float ok = __shfl_xor(key, j, WAVE);
+            const int os = __shfl_xor(src, j, WAVE);
+            const bool want_min = ((lane & j) == 0) == ((lane & k) == 0);
+            const bool other_less = ok < key || (ok == key && os < src);
+            if (want_min == other_less) { key = ok; src = os; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // The recurrence of train_rlvi.py:30-37 on one wave.  Lane j holds node j: its guess rn_l and the
 // totals tS = S(rn), tP = dS/dr(rn), tQ = -1/2 d2S/dr2(rn) (0: first-order correction only),
@@ -34,8 +55,10 @@ struct TjOut {
 // samples, for j < Ke (the evaluated nodes); Ka >= Ke nodes are kept in the state.  FIRST: the
 // sums were taken with e' = exp(-(l - shift)) and gmin (any lane's value is min-reduced here) is
 // the true minimum.  Results go to `out` (lane 0 / lanes < Ka); every lane must call.
+// HASQ: tQ is meaningful (second-order local model, quintic global model); otherwise first-order /
+// cubic.
 // ---------------------------------------------------------------------------------------
-template <bool FIRST>
+template <bool FIRST, bool HASQ = true>
 __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, double tP, double tQ,
                                          double tD,
                                          float gmin, bool dead, float rn_l, float shift, float invN,
@@ -96,22 +119,75 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
             r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
         }
     }
+    // (25 % trust region for the local model: inside it one more round finishes -- the bench's
+    //  data-to-data drift of 2-7 % stays on this path; beyond it the local model converges one
+    //  node per round at worst)
     const bool inside = !(has && lane < steps) ||
-                        (fabsf(rnew_l - rn) <= 0.5f * rn && avg_l > 0.0f && avg_l < 0.999999f);
+                        (fabsf(rnew_l - rn) <= RLVI_TJ_TRUST * rn && avg_l > 0.0f && avg_l < 0.999999f);
     if (!__all(inside)) {
+        // Cold or poor guesses: the nodes are far from the trajectory, but together they sample
+        // S(r) over its whole range.  s(u) = mean(pi) as a function of u = log r is a sum of
+        // logistic sigmoids -- smooth and monotone -- so a two-point Hermite interpolant between
+        // the evaluated nodes that bracket the current r (values, slopes and, with HASQ, second
+        // derivatives: quintic, error ~h^6/46080 |s^(6)| at spacing h = ln 2) gives every step of
+        // the recurrence to ~1e-5 whatever the guess was; the next round's local model finishes.
+        // Outside the sampled range: the damped local model of the nearest node (+-50 %).
+        float key = (has && rn > 0.0f && a0_l == a0_l) ? __logf(rn) : __builtin_inff();
+        int src = lane;
+        wave_sort_keys(key, src);
+        const float rn_s = __shfl(rn, src, WAVE);
+        const float s0_s = __shfl(a0_l, src, WAVE);
+        const float b_s = __shfl(b_l, src, WAVE);
+        const float c_s = __shfl(c_l, src, WAVE);
+        const float s1_s = rn_s * b_s;                                   // ds/du
+        const float s2_s = fmaf(-2.0f * rn_s * rn_s, c_s, s1_s);         // d2s/du2
+        const unsigned long long vmask = __ballot(key < __builtin_inff());
+        const int nv = (int)__popcll(vmask);
+        auto rl = [](float v, int p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), p)); };
         r = (float)(0.95 / (1.0 - 0.95));
 #pragma unroll 1
         for (int step = 0; step < steps; ++step) {
-            const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
-            const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
-            const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
-            const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_l), step));
             if (lane == step) rnew_l = r;
-            // damped step: the linearisation is trusted within +-50% of the node (S is concave
-            // in r, so the extrapolated mean stays positive); mean(pi) < 1
-            const float h = 0.5f * rns;
-            const float d = fmaxf(fminf(r - rns, h), -h);
-            const float avg = fminf(fmaf(d, fmaf(-cc, d, bb), a0), 0.999999f);
+            const float u = __logf(r);
+            const unsigned long long ge = __ballot(key >= u) & vmask;
+            const int p_hi = ge ? (int)__builtin_ctzll(ge) : nv;          // first node at or above r
+            float avg;
+            bool done = false;
+            if (p_hi > 0 && p_hi < nv) {
+                const float ua = rl(key, p_hi - 1), ub = rl(key, p_hi);
+                const float h = ub - ua;
+                if (h > 1e-5f) {
+                    const float sa = rl(s0_s, p_hi - 1), sb = rl(s0_s, p_hi);
+                    const float da = rl(s1_s, p_hi - 1), db = rl(s1_s, p_hi);
+                    const float t = (u - ua) * __builtin_amdgcn_rcpf(h);
+                    const float t2 = t * t, t3 = t2 * t;
+                    if (HASQ) {
+                        const float ea = rl(s2_s, p_hi - 1), eb = rl(s2_s, p_hi);
+                        const float w3 = t3 * fmaf(t, fmaf(6.0f, t, -15.0f), 10.0f);       // H3 = 1 - H0
+                        const float h1 = t - t3 * fmaf(t, fmaf(3.0f, t, -8.0f), 6.0f);
+                        const float h4 = t3 * fmaf(t, fmaf(-3.0f, t, 7.0f), -4.0f);
+                        const float h2 = 0.5f * t2 - t3 * fmaf(t, fmaf(0.5f, t, -1.5f), 1.5f);
+                        const float h5 = t3 * fmaf(t, fmaf(0.5f, t, -1.0f), 0.5f);
+                        avg = fmaf(w3, sb - sa, sa) + h * fmaf(da, h1, db * h4) +
+                              h * h * fmaf(ea, h2, eb * h5);
+                    } else {
+                        const float w3 = t2 * fmaf(-2.0f, t, 3.0f);                       // H3 = 1 - H0
+                        const float h1 = t - 2.0f * t2 + t3;
+                        const float h4 = t3 - t2;
+                        avg = fmaf(w3, sb - sa, sa) + h * fmaf(da, h1, db * h4);
+                    }
+                    done = true;
+                }
+            }
+            if (!done) {
+                // no bracket (or two coinciding nodes): damped local model of the nearest node
+                const int p = p_hi < nv ? p_hi : nv - 1;
+                const float rns = rl(rn_s, p), a0 = rl(s0_s, p), bb = rl(b_s, p), cc = rl(c_s, p);
+                const float hh = 0.5f * rns;
+                const float d = fmaxf(fminf(r - rns, hh), -hh);
+                avg = fmaf(d, fmaf(-cc, d, bb), a0);
+            }
+            avg = fminf(fmaxf(avg, 0.0f), 0.999999f);
             if (lane == step) avg_l = avg;
             r = fmaxf(avg * __builtin_amdgcn_rcpf(1.0f - avg), 1e-30f);              // (:31)
         }
