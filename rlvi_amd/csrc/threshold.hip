@@ -14,7 +14,9 @@
 // hence the boolean mask -- is bit-exact.  Ties are resolved arithmetically (multiplicity of the
 // crossing key).  ~32 block-wide reductions by one 1024-thread workgroup that holds the keys in
 // registers; latency-bound (N*4 B <= a few hundred KB), run once per epoch.
-#include "rlvi_common.h"
+#include <stdlib.h>
+
+#include "rlvi_coop.h"
 
 namespace rlvi {
 
@@ -323,6 +325,136 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_fast_kernel(float *__rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Cooperative form for populations beyond one workgroup's registers (N > 65 536: Food-101's
+// 75 750, web-scale label-noise sets of ~1e6): 240 workgroups of 256 threads hold N/240 keys each
+// in registers and run the SAME search with every block-wide reduction followed by one record
+// exchange (rlvi_coop.h: sums / min / max formed in a fixed order, identical on every workgroup;
+// the fp64 sums of multiples of 2^-24 are exact, so the order does not matter anyway).  An
+// exchange carries two values, so the search is ternary: two candidate keys per step, 19-20 steps
+// for the 2^30 candidate patterns instead of 30.  ~25 exchanges of ~2.6 us whatever N is, against
+// 0.39 ms (N = 75 750) ... 4.8 ms (N = 1e6) for one workgroup re-reading the keys from L2.
+// ---------------------------------------------------------------------------------------
+constexpr int THC_BLOCK = 256;
+constexpr int THC_G = 240;
+
+template <int E, bool TRUNC>
+__global__ __launch_bounds__(THC_BLOCK) void threshold_coop_kernel(float *__restrict__ w, int64_t N,
+                                                                   float alpha,
+                                                                   float *__restrict__ thr_io,
+                                                                   uint8_t *__restrict__ mask,
+                                                                   int64_t *__restrict__ kept_out,
+                                                                   void *ws) {
+    Coop<THC_BLOCK> coop;
+    coop.init(ws, (int)gridDim.x);
+    // (read before the first exchange: workgroup 0 overwrites it after the last one)
+    const float prev = TRUNC ? *thr_io : 0.0f;
+    const int64_t L = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t lo_i = (int64_t)blockIdx.x * L;
+    const int64_t hi_i = lo_i + L < N ? lo_i + L : N;
+    uint32_t k[E];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = lo_i + threadIdx.x + (int64_t)j * THC_BLOCK;
+        if (i < hi_i) { k[j] = f32_key(w[i]); cnt = j + 1; } else k[j] = 0;
+    }
+    auto for_each = [&](auto fn) {
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (j < cnt) fn(k[j], lo_i + threadIdx.x + (int64_t)j * THC_BLOCK);
+    };
+
+    // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44); global min / max key
+    double tot = 0.0, dmin = __builtin_inf(), dmax = -__builtin_inf(), zero = 0.0;
+    for_each([&](uint32_t key, int64_t) {
+        tot += one_minus(key);
+        dmin = (double)key < dmin ? (double)key : dmin;
+        dmax = (double)key > dmax ? (double)key : dmax;
+    });
+    coop.template allreduce2<OpSum, OpMin>(tot, dmin);
+    coop.template allreduce2<OpMax, OpSum>(dmax, zero);
+    const float beta = (float)tot * alpha;
+    const unsigned long long kmin = (unsigned long long)dmin, kmax = (unsigned long long)dmax;
+
+    // smallest c in [kmin, kmax+1] with fl32(S(c)) <= beta; invariant: the predicate holds at hi
+    unsigned long long lo = kmin, hi = kmax + 1ull;
+    const bool any_ok = 0.0f <= beta;           // S(kmax+1) = 0
+    while (any_ok && lo < hi && !coop.dead) {
+        const unsigned long long span = hi - lo;
+        const unsigned long long m1 = span >= 3 ? lo + span / 3 : lo + (span >> 1);
+        const unsigned long long m2 = span >= 3 ? lo + 2 * (span / 3) + 1 : hi;     // m1 < m2 <= hi
+        double s1 = 0.0, s2 = 0.0;
+        for_each([&](uint32_t key, int64_t) {
+            const double t = one_minus(key);
+            s1 += (key >= m1) ? t : 0.0;
+            s2 += (key >= m2) ? t : 0.0;
+        });
+        coop.template allreduce2<OpSum, OpSum>(s1, s2);
+        if ((float)s1 <= beta) hi = m1;
+        else if (m2 >= hi || (float)s2 <= beta) { lo = m1 + 1ull; hi = m2 < hi ? m2 : hi; }
+        else lo = m2 + 1ull;
+    }
+    const unsigned long long cstar = lo;
+
+    double s_in = 0.0, n_in = 0.0, above = __builtin_inf(), below = -1.0;   // min{k >= c*}, max{k < c*}
+    for_each([&](uint32_t key, int64_t) {
+        if (any_ok && key >= cstar) {
+            s_in += one_minus(key);
+            n_in += 1.0;
+            above = (double)key < above ? (double)key : above;
+        } else {
+            below = (double)key > below ? (double)key : below;
+        }
+    });
+    coop.template allreduce2<OpSum, OpSum>(s_in, n_in);
+    coop.template allreduce2<OpMin, OpMax>(above, below);
+    const double S = s_in, cnt_in = n_in;
+
+    float thr;
+    if (below < 0.0) {
+        thr = key_f32((uint32_t)kmin);           // every element is inside: count = N
+    } else {
+        const uint32_t v = (uint32_t)below;
+        double mult = 0.0;
+        zero = 0.0;
+        for_each([&](uint32_t key, int64_t) { mult += (key == v) ? 1.0 : 0.0; });
+        coop.template allreduce2<OpSum, OpSum>(mult, zero);
+        // j = #{i in 1..mult : fl32(S + i*t) <= beta}; monotone in i -> binary search
+        const double t = one_minus(v);
+        long long jl = 0, jh = (long long)mult;   // P(jl) true, P(jh) false (minimality of c*)
+        if (!any_ok) jh = 0;
+        while (jh - jl > 1) {
+            const long long jm = jl + ((jh - jl) >> 1);
+            if ((float)(S + (double)jm * t) <= beta) jl = jm; else jh = jm;
+        }
+        const long long j = any_ok ? jl : 0;
+        if (cnt_in + (double)j == 0.0) thr = key_f32((uint32_t)kmin);   // last_index = -1 wraps
+        else if (j >= 1) thr = key_f32(v);
+        else thr = key_f32((uint32_t)above);
+    }
+    if (TRUNC && !(thr > prev)) thr = prev;       // threshold = max(threshold, criterion)  (:102)
+
+    double kept = 0.0;
+    if (TRUNC) {
+        for_each([&](uint32_t key, int64_t i) {
+            float x = key_f32(key);
+            if (x < thr) { x = 0.0f; w[i] = 0.0f; }          // :103
+            const bool m = x > thr;                          // main.py:343
+            if (mask != nullptr) mask[i] = m ? 1 : 0;
+            kept += m ? 1.0 : 0.0;
+        });
+        zero = 0.0;
+        coop.template allreduce2<OpSum, OpSum>(kept, zero);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *thr_io = thr;
+        if (TRUNC && kept_out != nullptr) *kept_out = (int64_t)kept;
+        coop.finish(ws);
+    }
+}
+
 __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, int64_t N,
                                                        const float *__restrict__ thr_p,
                                                        uint8_t *__restrict__ mask) {
@@ -334,26 +466,33 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
     }
 }
 
-// Single workgroup.  N <= 65536: the integer fast form with the weights in registers (16 or 64
-// per thread); it hands over to the generic fp64 form (streaming, any N, any range) by setting a
-// flag the generic kernel reads at its start -- both are enqueued, the second is a no-op when the
-// first one succeeded.
+// N <= 16 384: one workgroup, the integer fast form with the weights in registers (16 per thread,
+// 40 us); it hands over to the generic fp64 form (any range) by setting a flag the generic kernel
+// reads at its start -- both are enqueued, the second is a no-op when the first one succeeded.
+// 16 384 < N <= 1 966 080: the cooperative form (85-120 us; one workgroup with 64 keys per thread
+// took 114-134 us up to 65 536 and 0.4-4.8 ms streaming beyond).  Larger: one workgroup, streaming.
 __global__ void threshold_flag_clear(int32_t *flag) { *flag = 0; }
 
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
                             int64_t *kept, void *ws, hipStream_t st) {
     int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
-    if (N <= (int64_t)THR_BLOCK * 64) {
+    static const int64_t coop_nmin = getenv("RLVI_THR_COOP_NMIN") ? atoll(getenv("RLVI_THR_COOP_NMIN")) : (int64_t)THR_BLOCK * 16 + 1;
+    if (N <= (int64_t)THR_BLOCK * 16 && N < coop_nmin) {
         hipLaunchKernelGGL(threshold_flag_clear, dim3(1), dim3(1), 0, st, flag);
-        if (N <= (int64_t)THR_BLOCK * 16)
-            hipLaunchKernelGGL((threshold_fast_kernel<16, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w,
-                               N, alpha, thr, mask, kept, flag);
-        else
-            hipLaunchKernelGGL((threshold_fast_kernel<64, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w,
-                               N, alpha, thr, mask, kept, flag);
+        hipLaunchKernelGGL((threshold_fast_kernel<16, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N,
+                           alpha, thr, mask, kept, flag);
         hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha,
                            thr, mask, kept, flag);
+    } else if (N <= (int64_t)THC_G * THC_BLOCK * 32) {
+        const int64_t L = (N + THC_G - 1) / THC_G;
+#define RLVI_THC(E_)                                                                             \
+    hipLaunchKernelGGL((threshold_coop_kernel<E_, TRUNC>), dim3(THC_G), dim3(THC_BLOCK), 0, st, w, \
+                       N, alpha, thr, mask, kept, ws)
+        if (L <= THC_BLOCK * 2) RLVI_THC(2);
+        else if (L <= THC_BLOCK * 8) RLVI_THC(8);
+        else RLVI_THC(32);
+#undef RLVI_THC
     } else {
         hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha,
                            thr, mask, kept, (const int32_t *)nullptr);

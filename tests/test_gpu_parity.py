@@ -266,9 +266,11 @@ def test_threshold_handmade_and_standalone(golden, gpu):
         assert int(kept) == int(g[f"x_{k}/kept"]), k
 
 
-@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 1023, 1025, 4097, 16385, 70001, 100003, 300000])
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 1023, 1025, 4097, 16385, 65536, 65537, 70001, 75750, 100003,
+                               122881, 300000, 1000003, 1966080, 1966081])
 def test_threshold_vs_oracle_sizes(N, gpu, oracle):
-    """All three key-storage paths (registers 16 / 80 per thread, streaming) + monotone max."""
+    """One workgroup (registers 16 / 64 per thread), 240 cooperating workgroups (2 / 8 / 32 keys per
+    thread, N > 65 536) and the streaming form (N > 1 966 080) + monotone max."""
     torch, ops, dev = gpu
     rng = np.random.default_rng(N)
     w = rng.random(N).astype(np.float32)
@@ -287,6 +289,7 @@ def test_threshold_vs_oracle_sizes(N, gpu, oracle):
     assert np.array_equal(wt.cpu().numpy(), w2)
     assert np.array_equal(mask.cpu().numpy(), m_ref)
     assert int(kept) == int(m_ref.sum())
+    assert ops.workspace(dev).status() == 0
 
 
 @pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 24575, 24576, 50000, 65536, 75750, 200000,

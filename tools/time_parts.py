@@ -30,7 +30,7 @@ if a.dtype == "bf16":
 if N != B:
     from rlvi_amd import synth
     residuals_n = torch.from_numpy(synth.residual_vector("bimodal", N, 1)).to(dev)
-    weights_n = torch.ones(N, device=dev)
+    weights_n = torch.rand(N, device=dev) if a.what == "thr" else torch.ones(N, device=dev)
 out = torch.empty(4, device=dev)
 iters = torch.zeros(1, dtype=torch.int32, device=dev)
 side = torch.cuda.Stream()
