@@ -52,6 +52,12 @@ class Workspace:
         return s.value
 
 
+def debug_scratch_offset():
+    """Byte offset of the workspace scratch area (where RLVI_TJ_DEBUG=1 leaves its stamps): the
+    fixed regions come first, so it is the size of a workspace for empty vectors minus its pad."""
+    return int(_lib.load().rlvi_workspace_bytes(0, 0)) - 256
+
+
 def workspace(device, n=0, b=0):
     """Per (device, stream) workspace, grown on demand."""
     device = torch.device(device)

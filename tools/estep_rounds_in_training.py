@@ -11,7 +11,7 @@ from rlvi_amd import driver, ops  # noqa: E402
 from rlvi_amd.methods import train_rlvi as _fn  # noqa: E402,F401
 import rlvi_amd.methods.train_rlvi  # noqa: E402,F401
 
-SCRATCH_OFF = 1024 + 16384 + 32768 + 512 + 32768 + (3 << 19) + 6144 + 262144   # WS_SCRATCH_OFF
+SCRATCH_OFF = ops.debug_scratch_offset()
 mod = sys.modules["rlvi_amd.methods.train_rlvi"]
 orig = ops.epoch_end
 dev = torch.device("cuda:0")

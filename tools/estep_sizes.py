@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from rlvi_amd import ops, synth  # noqa: E402
 
-SCRATCH_OFF = 1024 + 16384 + 32768 + 512 + 32768 + (3 << 19) + 6144 + 262144   # WS_SCRATCH_OFF
+SCRATCH_OFF = ops.debug_scratch_offset()
 
 dev = torch.device("cuda:0")
 for N in [int(a) for a in sys.argv[1:]]:

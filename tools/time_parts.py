@@ -93,7 +93,7 @@ with torch.cuda.stream(side):
     if os.environ.get("RLVI_TJ_DEBUG"):
         import numpy as np
         from rlvi_amd import _lib
-        off = 1024 + 16384 + 32768 + 512 + 32768 + (3 << 19) + 6144 + 262144      # WS_SCRATCH_OFF (rlvi_common.h)
+        off = ops.debug_scratch_offset()
         raw = ws.buf[off:off + 240 * 8].cpu().numpy().view(np.uint64)
         n = int(raw[63])
         st = raw[:n].astype(np.int64)
