@@ -387,16 +387,20 @@ def test_threshold_randomised_ties_and_ranges(gpu, oracle):
     assert dev_status(ops, dev) == 0
 
 
-def test_estep_cooperative_under_concurrent_load(gpu, oracle):
-    """The cooperative E-step needs its ~240 workgroups co-resident.  With another stream keeping
-    every CU busy (back-to-back GEMMs) its workgroups arrive unevenly; the exchange must neither
-    hang nor go stale: status stays 0 and the result is the oracle's."""
+@pytest.mark.parametrize("N", [65536, 524288])
+def test_cooperative_kernels_under_concurrent_load(N, gpu, oracle):
+    """The cooperative E-step and threshold kernels need their ~240 workgroups co-resident.  With
+    another stream keeping every CU busy (back-to-back GEMMs) their workgroups arrive unevenly; the
+    exchanges must neither hang nor go stale: status stays 0 and the results are the oracle's."""
     torch, ops, dev = gpu
-    N = 65536
     r = synth.residual_vector("bimodal", N, seed=3)
     rr, ww = r.copy(), np.ones(N, np.float32)
     it, err, _ = oracle.update_sample_weights(rr, ww, trace=True)
     assert np.min(np.abs(err - 1e-3)) > 1e-4 * 1e-3          # the stop decision is not a near-tie
+    wq = np.random.default_rng(5).random(N).astype(np.float32)
+    thr_ref = oracle.false_negative_criterion(wq)
+    wq_ref = wq.copy()
+    m_ref = oracle.truncate(wq_ref, thr_ref)
     a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
     side = torch.cuda.Stream()
     ws = ops.Workspace(dev, N, 0)
@@ -407,11 +411,15 @@ def test_estep_cooperative_under_concurrent_load(gpu, oracle):
         rt, wt = torch.from_numpy(r.copy()).to(dev), torch.ones(N, device=dev)
         iters = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.estep_deep(rt, wt, iters=iters, ws=ws)
+        wqt = torch.from_numpy(wq.copy()).to(dev)
+        thr, mask, kept = ops.threshold_truncate(wqt, 0.0, want_mask=True, ws=ws)
         torch.cuda.synchronize()
         assert ws.status() == 0
         assert int(iters) == it
         rel, small = rel_pi(wt.cpu().numpy(), ww)
         assert rel <= REL and small <= 1e-7
+        assert float(thr) == float(thr_ref)
+        assert np.array_equal(wqt.cpu().numpy(), wq_ref) and np.array_equal(mask.cpu().numpy(), m_ref)
 
 
 @pytest.mark.parametrize("N", [300, 5000, 30000])
