@@ -99,7 +99,10 @@ struct Coop {
     // the wave partials on.
     template <class OpA, class OpB, bool F32WAVE = false>
     __device__ __forceinline__ void allreduce2(double &a, double &b) {
+        constexpr int NPW = MAX_COOP_WG / WAVE;      // polling waves: one record per lane
+        static_assert(NW >= NPW, "the gather needs four waves");
         __shared__ double part[2 * NW];
+        __shared__ double part2[2 * NPW];
         __shared__ double bc[2];
         __shared__ int sh_dead;
         const int lane = threadIdx.x & (WAVE - 1);
@@ -112,14 +115,16 @@ struct Coop {
             b = wave_reduce<OpB>(b);
         }
         if (lane == 0) { part[2 * wave] = a; part[2 * wave + 1] = b; }
+        if (threadIdx.x == 0) sh_dead = dead ? 1 : 0;
         __syncthreads();
+        const bool xchg = nwg > 1 && !dead;          // uniform over the workgroup
+        gu64 *buf = slots + (size_t)(step & 1) * MAX_COOP_WG * XCHG_GRANULES;
         if (wave == 0) {
             double ta = lane < NW ? part[2 * lane] : OpA::ident();
             double tb = lane < NW ? part[2 * lane + 1] : OpB::ident();
             ta = wave_reduce<OpA>(ta);
             tb = wave_reduce<OpB>(tb);
-            if (nwg > 1 && !dead) {
-                gu64 *buf = slots + (size_t)(step & 1) * MAX_COOP_WG * XCHG_GRANULES;
+            if (xchg) {
                 // publish: lanes 0..3 store one granule each (32 contiguous bytes)
                 if (lane < XCHG_GRANULES) {
                     const unsigned long long bits =
@@ -129,63 +134,79 @@ struct Coop {
                                        ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // gather: lane l owns workgroups l, l+64, ...
-                double ga = OpA::ident(), gb = OpB::ident();
+            } else if (lane == 0) {
+                bc[0] = ta;
+                bc[1] = tb;
+            }
+        }
+        if (xchg) {
+            // gather: waves 0..3, lane l of wave v owns workgroup 64 v + l (all records in flight
+            // together); wave totals, then the four of them in a fixed order
+            if (wave < NPW) {
+                const int w = wave * WAVE + lane;
+                const bool mine = w < nwg;
+                gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG_GRANULES;
+                unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0;
                 const unsigned long long t0 = wall_clock64();
                 bool timeout = false;
-                for (int w = lane; w < ((nwg + WAVE - 1) / WAVE) * WAVE; w += WAVE) {
-                    unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-                    const bool mine = w < nwg;
-                    gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG_GRANULES;
-                    for (unsigned spin = 0;; ++spin) {
-                        bool ok = true;
-                        if (mine) {
-                            // the 32-byte record as two 16-byte sc1 loads (granule-atomic is enough:
-                            // every 8-byte granule carries its own tag)
-                            vu4_t q0, q1;
-                            asm volatile(
-                                "global_load_dwordx4 %0, %2, off sc1\n\t"
-                                "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
-                                "s_waitcnt vmcnt(0)"
-                                : "=&v"(q0), "=&v"(q1)
-                                : "v"((unsigned long long)(uintptr_t)p)
-                                : "memory");
-                            x0 = ((unsigned long long)q0.y << 32) | q0.x;
-                            x1 = ((unsigned long long)q0.w << 32) | q0.z;
-                            x2 = ((unsigned long long)q1.y << 32) | q1.x;
-                            x3 = ((unsigned long long)q1.w << 32) | q1.z;
-                            ok = (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag &&
-                                 (uint32_t)(x2 >> 32) == tag && (uint32_t)(x3 >> 32) == tag;
-                        }
-                        if (__all(ok)) break;
-                        // the wall clock is read only every 64 polls: keep the poll loop tight
-                        if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
-                            timeout = true;
-                            break;
-                        }
-                    }
-                    if (timeout) break;
+                for (unsigned spin = 0;; ++spin) {
+                    bool ok = true;
                     if (mine) {
-                        const double va = __longlong_as_double(
-                            (long long)(((x1 & 0xFFFFFFFFull) << 32) | (x0 & 0xFFFFFFFFull)));
-                        const double vb = __longlong_as_double(
-                            (long long)(((x3 & 0xFFFFFFFFull) << 32) | (x2 & 0xFFFFFFFFull)));
-                        ga = OpA::apply(ga, va);
-                        gb = OpB::apply(gb, vb);
+                        // the 32-byte record as two 16-byte sc1 loads (granule-atomic is enough:
+                        // every 8-byte granule carries its own tag)
+                        vu4_t q0, q1;
+                        asm volatile(
+                            "global_load_dwordx4 %0, %2, off sc1\n\t"
+                            "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                            "s_waitcnt vmcnt(0)"
+                            : "=&v"(q0), "=&v"(q1)
+                            : "v"((unsigned long long)(uintptr_t)p)
+                            : "memory");
+                        x0 = ((unsigned long long)q0.y << 32) | q0.x;
+                        x1 = ((unsigned long long)q0.w << 32) | q0.z;
+                        x2 = ((unsigned long long)q1.y << 32) | q1.x;
+                        x3 = ((unsigned long long)q1.w << 32) | q1.z;
+                        ok = (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag &&
+                             (uint32_t)(x2 >> 32) == tag && (uint32_t)(x3 >> 32) == tag;
+                    }
+                    if (__all(ok)) break;
+                    // the wall clock is read only every 64 polls: keep the poll loop tight
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                        timeout = true;
+                        break;
                     }
                 }
-                ta = wave_reduce<OpA>(ga);
-                tb = wave_reduce<OpB>(gb);
-                if (timeout) {
-                    dead = true;
-                    if (lane == 0) atomicOr(status, RLVI_ST_TIMEOUT);
+                double ga = OpA::ident(), gb = OpB::ident();
+                if (mine && !timeout) {
+                    ga = __longlong_as_double(
+                        (long long)(((x1 & 0xFFFFFFFFull) << 32) | (x0 & 0xFFFFFFFFull)));
+                    gb = __longlong_as_double(
+                        (long long)(((x3 & 0xFFFFFFFFull) << 32) | (x2 & 0xFFFFFFFFull)));
+                }
+                ga = wave_reduce<OpA>(ga);
+                gb = wave_reduce<OpB>(gb);
+                if (lane == 0) {
+                    part2[2 * wave] = ga;
+                    part2[2 * wave + 1] = gb;
+                    if (timeout) {
+                        sh_dead = 1;
+                        atomicOr(status, RLVI_ST_TIMEOUT);
+                    }
                 }
             }
-            if (lane == 0) { bc[0] = ta; bc[1] = tb; sh_dead = dead ? 1 : 0; }
+            __syncthreads();
+            a = part2[0];
+            b = part2[1];
+#pragma unroll
+            for (int v = 1; v < NPW; ++v) {
+                a = OpA::apply(a, part2[2 * v]);
+                b = OpB::apply(b, part2[2 * v + 1]);
+            }
+        } else {
+            __syncthreads();
+            a = bc[0];
+            b = bc[1];
         }
-        __syncthreads();
-        a = bc[0];
-        b = bc[1];
         dead = sh_dead != 0;
         ++step;
         ++tag;
