@@ -837,3 +837,27 @@ def test_cpp_host_program_over_the_c_abi(gpu, tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "-> ok" in p.stdout
+
+
+def test_bench_two_ranks_on_one_gpu(gpu):
+    """The N > 1 control flow of bench.py end to end on real kernels: two ranks share cuda:0, the
+    residual exchange goes through gloo (no RCCL peers on a one-GPU box); one JSON line, clean
+    device status, N = 2 x rows samples in the replicated E-step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "32768", "--backend", "gloo",
+                        "--same-device", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["device_status"] == 0
+    assert res["config"]["n_samples"] == 65536 and res["parts"]["estep_iters"] >= 1
+    assert res["value"] > 0
