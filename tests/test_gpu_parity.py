@@ -387,6 +387,43 @@ def test_threshold_randomised_ties_and_ranges(gpu, oracle):
     assert dev_status(ops, dev) == 0
 
 
+@pytest.mark.parametrize("N", [6000, 24576, 70001, 131072])
+def test_estep_random_walk_of_inputs_on_one_workspace(N, gpu, oracle):
+    """A long random sequence of very different loss vectors on ONE workspace: every call starts
+    from the previous call's (now arbitrary) trajectory -- scaled, shifted, mixed and degenerate
+    distributions, with random incoming weights.  Iteration count and pi must be the oracle's each
+    time, whatever the solver's path (local model, global model, damped steps)."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(1000 + N)
+    ws = ops.Workspace(dev, N, 0)
+    kinds = ["equal", "exp", "bimodal", "heavy", "zeros10", "ce"]
+    for trial in range(14):
+        r = synth.residual_vector(kinds[int(rng.integers(len(kinds)))], N, seed=int(rng.integers(1 << 30)))
+        mode = int(rng.integers(5))
+        if mode == 1:
+            r = r * np.float32(rng.choice([1e-3, 0.1, 10.0, 200.0]))        # scale
+        elif mode == 2:
+            r = r + np.float32(rng.choice([-30.0, 5.0, 1e4]))                # shift
+        elif mode == 3:
+            other = synth.residual_vector(kinds[int(rng.integers(len(kinds)))], N, seed=trial)
+            pick = rng.random(N) < 0.5
+            r = np.where(pick, r, other).astype(np.float32)                 # mixture
+        elif mode == 4:
+            r = np.round(r, 1).astype(np.float32)                           # heavy ties
+        w0 = rng.random(N).astype(np.float32) if trial % 2 else np.ones(N, np.float32)
+        rt, wt = torch.from_numpy(r.copy()).to(dev), torch.from_numpy(w0.copy()).to(dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=iters, ws=ws)
+        rr, ww = r.copy(), w0.copy()
+        it, err, _ = oracle.update_sample_weights(rr, ww, trace=True)
+        assert ws.status() == 0, (trial, mode)
+        if np.min(np.abs(err - 1e-3)) >= 1e-5 * 1e-3:
+            assert int(iters) == it, (trial, mode)
+            rel, small = rel_pi(wt.cpu().numpy(), ww)
+            assert rel <= REL and small <= 1e-7, (trial, mode)
+        assert np.array_equal(rt.cpu().numpy(), rr)
+
+
 @pytest.mark.parametrize("N", [65536, 524288])
 def test_cooperative_kernels_under_concurrent_load(N, gpu, oracle):
     """The cooperative E-step and threshold kernels need their ~240 workgroups co-resident.  With
