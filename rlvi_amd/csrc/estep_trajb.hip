@@ -5,7 +5,7 @@
 // for all nodes, a first-order corrected scalar recurrence, repeat until the nodes stop moving.
 // What changes is the decomposition.  There a workgroup owns ONE node and a sixth of the samples,
 // which stops fitting registers near 1e5 samples; here every workgroup owns a small slice of the
-// samples (N/240, registers) and evaluates ALL live nodes on it:
+// samples (N/256, registers) and evaluates ALL live nodes on it:
 //   * eight nodes at a time: per-thread partials of {sum r e/(1+r e), sum e/(1+r e)^2, sum e^2/(1+r e)^3,
 //     sum d^2} (the recurrence corrects S to second order in the node error), then a
 //     transposing butterfly (v_permlane32_swap / v_permlane16_swap / row_ror:8 halve the number of
@@ -14,7 +14,7 @@
 //   * only the nodes that matter are evaluated: Ke = (iterations of the previous call) + margin,
 //     grown when no stop index shows up among them;
 //   * the exchange has two stages: workgroup w publishes one 48-byte record per node (stage A);
-//     workgroup k < Ke gathers node k's 240 records, adds them in a fixed order and publishes the
+//     workgroup k < Ke gathers node k's 256 records, adds them in a fixed order and publishes the
 //     total (stage B); wave 0 of every workgroup reads the Ke totals (lane k = node k) and runs
 //     the recurrence.  Two ~2.5 us exchanges per round instead of K = 18-40 for the iteration.
 // Pads have e = 0 and drop out of every sum.  Per-thread and per-wave sums are fp32, cross-wave / cross-workgroup sums fp64 in a fixed
@@ -32,7 +32,12 @@ typedef unsigned int tb_vu4 __attribute__((ext_vector_type(4)));
 // Workgroup size: 256 threads = one wave per SIMD (the per-wave butterflies are a fixed cost per
 // wave and chunk, so fewer, fatter waves win as long as the slice fits the registers); the main loop
 // has no memory operations to hide and eight independent nodes of instruction-level parallelism.
-constexpr int TB_G = 240;            // exchanging workgroups (+1 for the epoch-end reduction)
+#ifndef RLVI_TB_G
+#define RLVI_TB_G 256
+#endif
+// 256 exchanging workgroups (+1 for the epoch-end reduction, which then shares a CU): at the bench
+// size a slice is exactly one sample per thread (32.6 us per step against 33.9 with 240).
+constexpr int TB_G = RLVI_TB_G;
 constexpr int TB_CHUNK = 8;
 constexpr int TB_NV = 5;             // values of a record: {S, P, Q, D, min}
 constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
