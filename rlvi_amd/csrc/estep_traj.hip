@@ -13,9 +13,10 @@
 // recurrence with the first-order correction S(r_k) ~ S(r'_k) + S'(r'_k)(r_k - r'_k).  The
 // corrected r_k become the next round's nodes.  Node 0 is exact, a node whose predecessor was
 // exact becomes exact, so m rounds fix at least m nodes (worst case = the iterative scheme); the
-// correction is Newton-like (second-order remainder <= 0.25 (dr/r)^2) and damped to a +-50 % trust
-// region, so from the previous call's trajectory (kept in the workspace) it takes 2-3 rounds, from
-// a cold or poor guess 4-9.  A round is accepted when max_k |r_k - r'_k| / r'_k <= 1e-6 over the
+// correction is Newton-like (second-order remainder <= 0.25 (dr/r)^2) inside a 25 % trust region;
+// outside it the recurrence runs on a global Hermite model of mean(pi) over log r built from ALL
+// evaluated nodes (rlvi_traj.h), so from the previous call's trajectory (kept in the workspace) it
+// takes 2 rounds and from a cold or poor guess 3.  A round is accepted when max_k |r_k - r'_k| / r'_k <= 1e-6 over the
 // executed iterations (S exact to ~1e-12, D -- evaluated AT the nodes -- to ~4e-6 relative), or
 // earlier when every stop test clears tol by 8x the uncertainty the remaining delta implies.
 // The minimum residual is not exchanged separately: round 0 evaluates with the previous call's

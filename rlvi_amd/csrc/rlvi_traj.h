@@ -104,7 +104,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     // (SGPR lane select, no LDS):  avg = a0 + b d - c d^2, d = r - r',  r <- avg / (1 - avg).
     // Fast form first (five dependent fp32 operations per step); its steps are then checked
     // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
-    // that left it (cold or poor guesses) is redone in the damped form.
+    // that left it (cold or poor guesses) is redone on the global model below.
     {
 #pragma unroll 1
         for (int step = 0; step < steps; ++step) {
