@@ -41,15 +41,15 @@ constexpr int TJ_NW = TJ_BLOCK / WAVE;
 constexpr int TJ_MAXS = 8;       // slices per node (one lane of the polling wave sweeps them)
 
 struct TjShared {
-    double part[TJ_NW][3];
-    double rec[MAX_COOP_WG][4];   // gathered records (wave 0 only)
+    double part[TJ_NW][4];
+    double rec[MAX_COOP_WG][5];   // gathered records {S, S', Q, D, min} (wave 0 only)
     float pmin[TJ_NW];
     TjOut out;
 };
 
 // ---------------------------------------------------------------------------------------
 // One round's communication + the scalar recurrence.  Workgroup b = k*S + s publishes
-// {S, S', D, min} as 8 self-tagged granules; waves 0..3 sweep the K*S records (one 64-byte record
+// {S (fp64: two granules), S', Q = -S''/2, D, min (fp32: one each)} as self-tagged granules; waves 0..3 sweep the K*S records (one 64-byte record
 // per lane, four 16-byte sc1 loads in flight) into LDS; lane k of wave 0 adds node k's S records in
 // slice order and runs node k's part of the recurrence (the other waves wait at the closing
 // barrier).  Protocol as in rlvi_coop.h (sc1 stores / loads, parity slots, tags from the
@@ -57,7 +57,8 @@ struct TjShared {
 // ---------------------------------------------------------------------------------------
 
 template <bool FIRST>
-__device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float fD, float fmin_,
+__device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float fQ, float fD,
+                                         float fmin_,
                                          gu64 *slots, uint32_t tag, int xstep, int K, int S,
                                          int32_t *status, bool &dead, float rn_l, float shift,
                                          float invN, float tol, float *trace, bool want_nodes,
@@ -68,16 +69,18 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
     // ~1e-7 relative, below the fp32 rounding of mean(pi) itself), fp64 across waves / workgroups
     const float a = group_allreduce<WAVE>(fS, FAdd());
     const float b = group_allreduce<WAVE>(fP, FAdd());
-    const float c = group_allreduce<WAVE>(fD, FAdd());
+    const float c = group_allreduce<WAVE>(fQ, FAdd());
+    const float d4 = group_allreduce<WAVE>(fD, FAdd());
     float mn = FIRST ? group_allreduce<WAVE>(fmin_, FMin()) : 0.0f;
     if (lane == 0) {
         sh.part[wave][0] = (double)a; sh.part[wave][1] = (double)b; sh.part[wave][2] = (double)c;
+        sh.part[wave][3] = (double)d4;
         if (FIRST) sh.pmin[wave] = mn;
     }
     __syncthreads();
 #define TJ_RS(i) do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && xstep < 4) dbg[200 + xstep * 8 + (i)] = wall_clock64(); } while (0)
     TJ_RS(0);
-    constexpr int NQ = FIRST ? 8 : 6;
+    constexpr int NQ = FIRST ? 6 : 5;                // granules: S lo, S hi, S', Q, D, (min)
     constexpr int PER = MAX_COOP_WG / WAVE;          // polling waves (one record per lane each)
     auto dbl = [](unsigned long long lo, unsigned long long hi) {
         return __longlong_as_double((long long)(((hi & 0xFFFFFFFFull) << 32) | (lo & 0xFFFFFFFFull)));
@@ -87,15 +90,21 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
     if (wave == 0 && !dead) {
         double t[4];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const double v = lane < TJ_NW ? sh.part[lane][q] : 0.0;
             t[q] = group_allreduce<WAVE>(v, FAdd());
         }
-        t[3] = FIRST ? (double)group_allreduce<WAVE>(lane < TJ_NW ? sh.pmin[lane] : __builtin_inff(), FMin())
-                     : 0.0;
-        if (lane < 8) {
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(t[lane >> 1]);
-            const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        const float tmin = FIRST ? group_allreduce<WAVE>(lane < TJ_NW ? sh.pmin[lane] : __builtin_inff(), FMin())
+                                 : 0.0f;
+        if (lane < NQ) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(t[0]);
+            uint32_t half;
+            if (lane == 0) half = (uint32_t)bits;
+            else if (lane == 1) half = (uint32_t)(bits >> 32);
+            else if (lane == 2) half = __float_as_uint((float)t[1]);
+            else if (lane == 3) half = __float_as_uint((float)t[2]);
+            else if (lane == 4) half = __float_as_uint((float)t[3]);
+            else half = __float_as_uint(tmin);
             __hip_atomic_store(buf + (size_t)blockIdx.x * XCHG2_GRANULES + lane,
                                ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -142,8 +151,9 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
         if (timeout) {
             if (lane == 0) { atomicOr(status, RLVI_ST_TIMEOUT); sh.out.dead = 1; }
         } else if (mine) {
+            sh.rec[w][0] = dbl(x[0], x[1]);
 #pragma unroll
-            for (int q = 0; q < NQ / 2; ++q) sh.rec[w][q] = dbl(x[2 * q], x[2 * q + 1]);
+            for (int q = 1; q < NQ - 1; ++q) sh.rec[w][q] = (double)__uint_as_float((uint32_t)x[q + 1]);
         }
     }
     TJ_RS(2);
@@ -151,19 +161,20 @@ __device__ __forceinline__ void tj_round(TjShared &sh, float fS, float fP, float
     TJ_RS(3);
     dead = dead || sh.out.dead != 0;
     if (wave == 0) {
-        double tS = 0.0, tP = 0.0, tD = 0.0;
+        double tS = 0.0, tP = 0.0, tQ = 0.0, tD = 0.0;
         float gmin = __builtin_inff();
         if (!dead && lane < K) {
             for (int ss = 0; ss < S; ++ss) {              // fixed order over the slices
                 const int w = lane * S + ss;
                 tS += sh.rec[w][0];
                 tP += sh.rec[w][1];
-                tD += sh.rec[w][2];
-                if constexpr (FIRST) gmin = fminf(gmin, (float)sh.rec[w][3]);
+                tQ += sh.rec[w][2];
+                tD += sh.rec[w][3];
+                if constexpr (FIRST) gmin = fminf(gmin, (float)sh.rec[w][4]);
             }
         }
         TJ_RS(4);
-        tj_chain<FIRST, false>(sh.out, K, K, tS, tP, 0.0, tD, gmin, dead, rn_l, shift, invN, tol, trace,
+        tj_chain<FIRST, true>(sh.out, K, K, tS, tP, tQ, tD, gmin, dead, rn_l, shift, invN, tol, trace,
                         want_nodes, xstep, dbg);
         TJ_RS(6);
     }
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
     bool accepted = false;
     for (int round = 0; round <= K + 1; ++round) {
         // ---- sums of this workgroup's node over its slice
-        float fS = 0.0f, fP = 0.0f, fD = 0.0f;
+        float fS = 0.0f, fP = 0.0f, fQ = 0.0f, fD = 0.0f;
         auto body = [&](float ev, float wv) {
             const float t = r_mine * ev;
             const float inv = __builtin_amdgcn_rcpf(1.0f + t);
@@ -251,7 +262,9 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
             else { const float tp = r_prev * ev; fp = tp * __builtin_amdgcn_rcpf(1.0f + tp); }
             const float d = f - fp;
             fS += f;
-            fP += ev * inv * inv;
+            const float xq = ev * inv, yq = xq * inv;
+            fP += yq;                                      // e/(1+re)^2
+            fQ = fmaf(xq, yq, fQ);                         // e^2/(1+re)^3
             fD += d * d;
         };
         if (E > 0) {
@@ -280,10 +293,10 @@ __global__ __launch_bounds__(TJ_BLOCK) void estep_traj_kernel(
         }
         TJ_STAMP();   // sums done
         if (round == 0)
-            tj_round<true>(sh, fS, fP, fD, mn, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
+            tj_round<true>(sh, fS, fP, fQ, fD, mn, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
                            shift, invN, tol, trace, true, dbg);
         else
-            tj_round<false>(sh, fS, fP, fD, 0.0f, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
+            tj_round<false>(sh, fS, fP, fQ, fD, 0.0f, slots, tag, xstep, K, S, &hdr->status, dead, rn_l,
                             shift, invN, tol, trace, true, dbg);
         ++tag; ++xstep;
         TJ_STAMP();   // exchange + recurrence done
