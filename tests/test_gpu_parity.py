@@ -898,3 +898,51 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["device_status"] == 0
     assert res["config"]["n_samples"] == 65536 and res["parts"]["estep_iters"] >= 1
     assert res["value"] > 0
+
+
+def test_epoch_end_with_truncation_is_graph_capturable(gpu, oracle):
+    """E-step + type-II threshold + truncation (train_rlvi.py:99-103) captured in ONE hipGraph and
+    replayed on fresh data: no host synchronisation, no allocation the capture cannot hold, same
+    results as the oracle on every replay (the cooperative kernels keep their tags in the
+    workspace, so replays do not collide)."""
+    torch, ops, dev = gpu
+    N = 75750
+    ws = ops.Workspace(dev, N, 0)
+    res = torch.empty(N, device=dev)
+    wts = torch.empty(N, device=dev)
+    thr = torch.zeros(1, device=dev)
+    mask = torch.empty(N, dtype=torch.uint8, device=dev)
+    kept = torch.zeros(1, dtype=torch.int64, device=dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = __import__("rlvi_amd._lib", fromlist=["load"]).load()
+    side = torch.cuda.Stream()
+
+    def enqueue():
+        st = ops._stream_ptr()
+        assert L.rlvi_estep_deep_f32(ops._ptr(res), ops._ptr(wts), N, 1e-3, 40, ops._ptr(iters), None, ws.ptr, st) == 0
+        assert L.rlvi_threshold_truncate_f32(ops._ptr(wts), N, 0.05, ops._ptr(thr), ops._ptr(mask),
+                                             ops._ptr(kept), ws.ptr, st) == 0
+
+    data = [synth.residual_vector(k, N, seed=s) for k, s in (("bimodal", 1), ("exp", 2), ("zeros10", 3))]
+    with torch.cuda.stream(side):
+        res.copy_(torch.from_numpy(data[0])); wts.fill_(1.0); thr.zero_()
+        enqueue()                                          # warm-up outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            enqueue()
+        for r in data:
+            res.copy_(torch.from_numpy(r)); wts.fill_(1.0); thr.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            rr, ww = r.copy(), np.ones(N, np.float32)
+            it = oracle.update_sample_weights(rr, ww)
+            t_ref = oracle.false_negative_criterion(ww)
+            m_ref = oracle.truncate(ww, t_ref)
+            assert ws.status() == 0 and int(iters) == it
+            # the threshold is taken on the GPU's own pi (a few 1e-7 from the oracle's), so it is the
+            # oracle's up to that, and so is the number of samples on the other side of it
+            assert abs(float(thr) - float(t_ref)) <= 1e-5 * max(float(t_ref), 1e-30)
+            assert abs(int(kept) - int(m_ref.sum())) <= 2
+            got = wts.cpu().numpy()
+            assert np.array_equal(mask.cpu().numpy().astype(bool), got > float(thr))
