@@ -100,12 +100,42 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     float r = (float)(0.95 / (1.0 - 0.95));
     float rnew_l = rn;
     float avg_l = 0.0f;
+    // Verification rounds first, without the serial loop: when the nodes already (almost) satisfy
+    // the recurrence, the relative deviation eps_k = (r_k - r'_k)/r'_k of the true chain obeys the
+    // LINEAR recurrence  eps_{k+1} = rho_k + s_k eps_k,  rho_k = (g(a0_k) - r'_{k+1})/r'_{k+1},
+    // s_k = b_k r'_k / ((1 - a0_k)^2 r'_{k+1})  (second-order terms ~20 eps^2), which is an affine
+    // scan over the lanes: six shuffle steps instead of it+2 dependent iterations.
+    bool scanned = false;
+    if (!FIRST) {
+        const float om = 1.0f - a0_l;
+        const float iom = __builtin_amdgcn_rcpf(om);
+        const float rn_next = __shfl_down(rn, 1, WAVE);
+        const float irn = __builtin_amdgcn_rcpf(rn_next);
+        const bool act = has && lane + 1 < steps;
+        float sc = act ? b_l * rn * iom * iom * irn : 0.0f;            // s_k
+        float of = act ? (a0_l * iom - rn_next) * irn : 0.0f;          // rho_k
+        if (lane == 0) of = fmaf(sc, (r - rn) * __builtin_amdgcn_rcpf(rn), of);   // eps_0 (r_0 is exact)
+#pragma unroll
+        for (int sh = 1; sh < WAVE; sh <<= 1) {                        // inclusive scan of x -> sc x + of
+            const float psc = __shfl_up(sc, sh, WAVE);
+            const float pof = __shfl_up(of, sh, WAVE);
+            if (lane >= sh) { of = fmaf(sc, pof, of); sc *= psc; }
+        }
+        float eps = __shfl_up(of, 1, WAVE);                            // lane k: eps_k
+        if (lane == 0) eps = (r - rn) * __builtin_amdgcn_rcpf(rn);
+        const float emax = group_allreduce<WAVE>((has && lane < steps) ? fabsf(eps) : 0.0f, FMax());
+        if (emax <= 3e-5f) {                                           // (NaN compares false)
+            scanned = true;
+            rnew_l = fmaf(rn, eps, rn);
+            avg_l = fmaf(b_l * rn, eps, a0_l);
+        }
+    }
     // serial chain; `step` is wave-uniform, so the per-node values come through v_readlane
     // (SGPR lane select, no LDS):  avg = a0 + b d - c d^2, d = r - r',  r <- avg / (1 - avg).
     // Fast form first (five dependent fp32 operations per step); its steps are then checked
     // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
     // that left it (cold or poor guesses) is redone on the global model below.
-    {
+    if (!scanned) {
 #pragma unroll 1
         for (int step = 0; step < steps; ++step) {
             const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
