@@ -232,7 +232,9 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         TB_STAMP();   // sums done
         __syncthreads();
         gu64 *A = bufA + (size_t)(xstep & 1) * TJ_MAXK * MAX_COOP_WG * XCHG3_GRANULES;
-        gu64 *B = bufB + (size_t)(xstep & 1) * TJ_MAXK * XCHG3_GRANULES;
+        // (every replica on its own 3-KiB stretch: 256 pollers on one 768-byte stretch serialise at the
+        //  memory side)
+        gu64 *B = bufB + (size_t)(xstep & 1) * XCHG3B_REPLICAS * TJ_MAXK * XCHG3_GRANULES;
         const int nq = round == 0 ? 5 : 4;
         // ---- stage A: this workgroup's record of every evaluated node
         if (wave == 0 && !dead && lane < Ke) {
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                     tM = sh.red[w][4] < tM ? sh.red[w][4] : tM;
                 }
                 const float rec[TB_NV] = {(float)tS, (float)tP, (float)tQ, (float)tD, (float)tM};
-                if (lane == 0) store_rec(B + (size_t)b * XCHG3_GRANULES, tag, nq, rec);
+                if (lane < XCHG3B_REPLICAS)
+                    store_rec(B + ((size_t)lane * TJ_MAXK + b) * XCHG3_GRANULES, tag, nq, rec);
             }
         }
         TB_STAMP();   // published
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
             float val[TB_NV] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             if (!dead) {
                 const bool mine = lane < Ke;
-                gu64 *p = B + (size_t)(mine ? lane : 0) * XCHG3_GRANULES;
+                gu64 *p = B + ((size_t)(b & (XCHG3B_REPLICAS - 1)) * TJ_MAXK + (mine ? lane : 0)) * XCHG3_GRANULES;
                 const unsigned long long t0 = wall_clock64();
                 bool timeout = false;
                 for (unsigned spin = 0;; ++spin) {

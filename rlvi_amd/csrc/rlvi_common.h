@@ -43,7 +43,11 @@ constexpr int XCHG3_GRANULES = 6;
 constexpr size_t WS_XCHG3A_OFF = WS_PART_OFF + WS_PART_BYTES;
 constexpr size_t WS_XCHG3A_BYTES = 2ull * 64 * MAX_COOP_WG * XCHG3_GRANULES * 8;   // 1.5 MiB
 constexpr size_t WS_XCHG3B_OFF = WS_XCHG3A_OFF + WS_XCHG3A_BYTES;
-constexpr size_t WS_XCHG3B_BYTES = 2ull * 64 * XCHG3_GRANULES * 8;                 // 6 KiB
+#ifndef RLVI_XCHG3B_REPLICAS
+#define RLVI_XCHG3B_REPLICAS 8
+#endif
+constexpr int XCHG3B_REPLICAS = RLVI_XCHG3B_REPLICAS;     // the per-node totals are published in 8 copies (one per 32 pollers)
+constexpr size_t WS_XCHG3B_BYTES = 2ull * XCHG3B_REPLICAS * 64 * XCHG3_GRANULES * 8;   // 48 KiB
 // partial Gram matrices of the weighted-least-squares kernel: 8 workgroups x 64 x 64 doubles
 constexpr size_t WS_WLS_OFF = WS_XCHG3B_OFF + WS_XCHG3B_BYTES;
 constexpr int WLS_MAX_WG = 8;
