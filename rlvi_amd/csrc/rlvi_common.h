@@ -25,7 +25,10 @@ struct WsHeader {
 constexpr size_t WS_HDR_BYTES = sizeof(WsHeader);                       // 768
 constexpr size_t WS_XCHG_OFF = 1024;
 constexpr int XCHG_GRANULES = 4;                                        // per workgroup
-constexpr size_t WS_XCHG_BYTES = 2ull * MAX_COOP_WG * XCHG_GRANULES * 8; // 2 parities, 16 KiB
+// every record is published in XCHG_REPLICAS copies and a workgroup polls copy (blockIdx % 8): 256
+// pollers on the same lines serialise at the memory side
+constexpr int XCHG_REPLICAS = 8;
+constexpr size_t WS_XCHG_BYTES = 2ull * XCHG_REPLICAS * MAX_COOP_WG * XCHG_GRANULES * 8; // 128 KiB
 // second exchange region: 8-granule records (three doubles) of the trajectory E-step
 constexpr int XCHG2_GRANULES = 8;
 constexpr size_t WS_XCHG2_OFF = WS_XCHG_OFF + WS_XCHG_BYTES;

@@ -62,7 +62,7 @@ constexpr unsigned long long SPIN_BOUND_TICKS = 200000000ull;   // 2 s of the 10
 
 template <int BLOCK>
 struct Coop {
-    gu64 *slots;        // [2][MAX_COOP_WG][XCHG_GRANULES]
+    gu64 *slots;        // [2][XCHG_REPLICAS][MAX_COOP_WG][XCHG_GRANULES]
     int32_t *status;
     uint32_t tag;       // tag of the NEXT exchange
     int step;           // exchanges done so far
@@ -118,19 +118,20 @@ struct Coop {
         if (threadIdx.x == 0) sh_dead = dead ? 1 : 0;
         __syncthreads();
         const bool xchg = nwg > 1 && !dead;          // uniform over the workgroup
-        gu64 *buf = slots + (size_t)(step & 1) * MAX_COOP_WG * XCHG_GRANULES;
+        gu64 *buf = slots + (size_t)(step & 1) * XCHG_REPLICAS * MAX_COOP_WG * XCHG_GRANULES;
         if (wave == 0) {
             double ta = lane < NW ? part[2 * lane] : OpA::ident();
             double tb = lane < NW ? part[2 * lane + 1] : OpB::ident();
             ta = wave_reduce<OpA>(ta);
             tb = wave_reduce<OpB>(tb);
             if (xchg) {
-                // publish: lanes 0..3 store one granule each (32 contiguous bytes)
-                if (lane < XCHG_GRANULES) {
+                // publish: lane l stores granule l & 3 (32 contiguous bytes) of replica l >> 2
+                if (lane < XCHG_GRANULES * XCHG_REPLICAS) {
+                    const int gq = lane & (XCHG_GRANULES - 1), rep = lane / XCHG_GRANULES;
                     const unsigned long long bits =
-                        (unsigned long long)__double_as_longlong(lane < 2 ? ta : tb);
-                    const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-                    __hip_atomic_store(buf + (size_t)blockIdx.x * XCHG_GRANULES + lane,
+                        (unsigned long long)__double_as_longlong(gq < 2 ? ta : tb);
+                    const uint32_t half = (gq & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+                    __hip_atomic_store(buf + ((size_t)rep * MAX_COOP_WG + blockIdx.x) * XCHG_GRANULES + gq,
                                        ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -145,7 +146,8 @@ struct Coop {
             if (wave < NPW) {
                 const int w = wave * WAVE + lane;
                 const bool mine = w < nwg;
-                gu64 *p = buf + (size_t)(mine ? w : 0) * XCHG_GRANULES;
+                gu64 *p = buf + ((size_t)(blockIdx.x & (XCHG_REPLICAS - 1)) * MAX_COOP_WG + (mine ? w : 0)) *
+                                XCHG_GRANULES;
                 unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0;
                 const unsigned long long t0 = wall_clock64();
                 bool timeout = false;
