@@ -237,18 +237,22 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         gu64 *B = bufB + (size_t)(xstep & 1) * XCHG3B_REPLICAS * TJ_MAXK * XCHG3_GRANULES;
         const int nq = round == 0 ? 5 : 4;
         // ---- stage A: this workgroup's record of every evaluated node
-        if (wave == 0 && !dead && lane < Ke) {
-            double dI = 0.0, dP = 0.0, dQ = 0.0, dD = 0.0;
+        // (waves 0..3 each combine the wave partials and store ONE granule per lane -- S, S', Q, D;
+        //  a lane's write-through stores go out one after the other)
+        if (wave < 4 && !dead && lane < Ke) {
+            double dq = 0.0;
 #pragma unroll
-            for (int w = 0; w < TB_NW; ++w) {
-                const float4 v = *reinterpret_cast<const float4 *>(sh.wp[w][lane]);
-                dI += (double)v.x; dP += (double)v.y; dQ += (double)v.z; dD += (double)v.w;
+            for (int w = 0; w < TB_NW; ++w) dq += (double)sh.wp[w][lane][wave];
+            gu64 *rec = A + ((size_t)lane * MAX_COOP_WG + b) * XCHG3_GRANULES;
+            __hip_atomic_store(rec + wave, ((unsigned long long)tag << 32) | __float_as_uint((float)dq),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0 && nq > 4) {
+                float wmin = sh.pmin[0];
+#pragma unroll
+                for (int w = 1; w < TB_NW; ++w) wmin = fminf(wmin, sh.pmin[w]);
+                __hip_atomic_store(rec + 4, ((unsigned long long)tag << 32) | __float_as_uint(wmin),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            float wmin = sh.pmin[0];
-#pragma unroll
-            for (int w = 1; w < TB_NW; ++w) wmin = fminf(wmin, sh.pmin[w]);
-            const float rec[TB_NV] = {(float)dI, (float)dP, (float)dQ, (float)dD, wmin};
-            store_rec(A + ((size_t)lane * MAX_COOP_WG + b) * XCHG3_GRANULES, tag, nq, rec);
         }
         TB_STAMP();   // stage A stored
         // ---- stage B: workgroup k < Ke adds node k's records and publishes the total
@@ -290,9 +294,15 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                     tS += sh.red[w][0]; tP += sh.red[w][1]; tQ += sh.red[w][2]; tD += sh.red[w][3];
                     tM = sh.red[w][4] < tM ? sh.red[w][4] : tM;
                 }
-                const float rec[TB_NV] = {(float)tS, (float)tP, (float)tQ, (float)tD, (float)tM};
-                if (lane < XCHG3B_REPLICAS)
-                    store_rec(B + ((size_t)lane * TJ_MAXK + b) * XCHG3_GRANULES, tag, nq, rec);
+                // lane l stores granule l & 7 of replica l >> 3: one store per lane
+                static_assert(XCHG3B_REPLICAS * 8 == WAVE && TB_NV <= 8, "one granule of one replica per lane");
+                const int gq = lane & 7;
+                const float val = gq == 0 ? (float)tS : gq == 1 ? (float)tP : gq == 2 ? (float)tQ
+                                  : gq == 3 ? (float)tD : (float)tM;
+                if (gq < nq)
+                    __hip_atomic_store(B + ((size_t)(lane >> 3) * TJ_MAXK + b) * XCHG3_GRANULES + gq,
+                                       ((unsigned long long)tag << 32) | __float_as_uint(val),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         TB_STAMP();   // published
