@@ -79,7 +79,7 @@ def test_mstep_bf16_golden(key, golden, gpu):
 
 @pytest.mark.parametrize("B,C", [(1, 1), (1, 2), (3, 3), (7, 5), (65, 7), (129, 10), (1000, 33),
                                  (257, 100), (513, 101), (300, 256), (130, 260), (70, 1000),
-                                 (33, 2048)])
+                                 (33, 2048), (200, 102), (300, 127), (100, 66), (4100, 37), (2, 129)])
 def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     """Ragged batches and every (vector width, lane group, chunks) dispatch of the kernel."""
     d = synth.mstep_inputs(B, C, N=B + 17, seed=B * 7 + C, zero_frac=0.1)
