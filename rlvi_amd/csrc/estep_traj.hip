@@ -390,7 +390,7 @@ int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxi
                           int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                           float *mstep_out, double mstep_scale, int *rc) {
     static const int mode = getenv("RLVI_ESTEP_TRAJ") ? atoi(getenv("RLVI_ESTEP_TRAJ")) : 1;
-    // (from 24 576 samples on estep_trajb.hip is tried first and wins; this bound only matters when
+    // (from 12 288 samples on estep_trajb.hip is tried first and wins; this bound only matters when
     //  that kernel is switched off)
     static const int64_t nmax = getenv("RLVI_ESTEP_TRAJ_NMAX") ? atoll(getenv("RLVI_ESTEP_TRAJ_NMAX")) : 200000;
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < 4096 || N > nmax) return 0;

@@ -399,13 +399,13 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
 }
 
 // Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if not applicable.
-// Measured crossover against the node-per-workgroup kernel (whole step, hipGraph): 24.1 vs 29.9 us
-// at N = 16 384, 34.1 vs 31.4 us at 32 768, 42.1 vs 36.1 us at 65 536, 60.7 vs 46.2 us at 131 072.
+// Measured crossover against the node-per-workgroup kernel (whole step, hipGraph): 21.8 vs 22.9 us
+// at N = 4096, 21.6 vs 22.1 us at 8192, 25.2 vs 24.0 us at 16 384, 42.1 vs 28.9 us at 65 536.
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                            float *mstep_out, double mstep_scale, int *rc) {
     static const int mode = getenv("RLVI_ESTEP_TRAJB") ? atoi(getenv("RLVI_ESTEP_TRAJB")) : 1;
-    static const int64_t nmin = getenv("RLVI_ESTEP_TRAJB_NMIN") ? atoll(getenv("RLVI_ESTEP_TRAJB_NMIN")) : 24576;
+    static const int64_t nmin = getenv("RLVI_ESTEP_TRAJB_NMIN") ? atoll(getenv("RLVI_ESTEP_TRAJB_NMIN")) : 12288;
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin || N < TB_G) return 0;
     const int64_t L = (N + TB_G - 1) / TB_G;
     if (L > 8192) return 0;

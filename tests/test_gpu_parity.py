@@ -292,11 +292,11 @@ def test_threshold_vs_oracle_sizes(N, gpu, oracle):
     assert ops.workspace(dev).status() == 0
 
 
-@pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 24575, 24576, 50000, 65536, 75750, 200000,
+@pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 12287, 12288, 24576, 50000, 65536, 75750, 200000,
                                200001, 262144, 524288, 600000, 1000003, 1966080, 2097152, 2097153])
 def test_estep_vs_oracle_sizes(N, gpu, oracle):
-    """Iterative (N < 4096, N > 2 097 152), node-per-workgroup trajectory (4096..24 575) and
-    slice-per-workgroup trajectory (24 576..2 097 152) solvers.
+    """Iterative (N < 4096, N > 2 097 152), node-per-workgroup trajectory (4096..12 287) and
+    slice-per-workgroup trajectory (12 288..2 097 152) solvers.
 
     Determinism: from the same workspace state two runs are bit-identical (fixed reduction
     order -- this is also the race detector).  The trajectory solver warm-starts from the last
