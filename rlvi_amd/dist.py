@@ -20,6 +20,9 @@ import torch
 import torch.distributed as dist
 
 
+_INPLACE_GATHER = True
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -58,6 +61,15 @@ def exchange_residuals_owned(residuals, start, stop, group=None, force=False):
         dist.all_gather_into_tensor(host, residuals[start:stop].cpu(), group=group)
         residuals.copy_(host)
         return
+    # RCCL / NCCL gather in place when the send buffer is this rank's own slice of the receive
+    # buffer; if a torch build refuses overlapping tensors, fall back to a copy of the slice (once)
+    global _INPLACE_GATHER
+    if _INPLACE_GATHER:
+        try:
+            dist.all_gather_into_tensor(residuals, residuals[start:stop], group=group)
+            return
+        except (RuntimeError, ValueError):
+            _INPLACE_GATHER = False
     dist.all_gather_into_tensor(residuals, residuals[start:stop].clone(), group=group)
 
 
