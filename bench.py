@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--dist-graph", default="off", choices=["auto", "off"],
                     help="world > 1: 'auto' captures the RCCL all-gather in the hipGraph too (and falls "
                          "back to eager launches on every rank if any rank cannot).  Default off: the "
-                         "eager loop costs ~45 us of host time per step, about what the GPU needs at "
+                         "eager loop costs ~37 us of host time per step, less than the GPU needs at "
                          "2+ ranks, and an eager RCCL call cannot hang a replay")
     ap.add_argument("--force-collective", action="store_true",
                     help="debug: run the residual exchange (and its process group) at world size 1")
