@@ -277,9 +277,11 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                 }
                 TB_STAMP();   // stage A gathered
                 const double vS = group_allreduce<WAVE>(mine ? (double)val[0] : 0.0, FAdd());
-                const double vP = group_allreduce<WAVE>(mine ? (double)val[1] : 0.0, FAdd());
-                const double vQ = group_allreduce<WAVE>(mine ? (double)val[2] : 0.0, FAdd());
-                const double vD = group_allreduce<WAVE>(mine ? (double)val[3] : 0.0, FAdd());
+                // (S steers the trajectory: fp64; the slopes and the step error are fine in fp32 -- one
+                //  fused v_add_f32_dpp per butterfly step instead of two moves and an fp64 add)
+                const double vP = (double)group_allreduce<WAVE>(mine ? val[1] : 0.0f, FAdd());
+                const double vQ = (double)group_allreduce<WAVE>(mine ? val[2] : 0.0f, FAdd());
+                const double vD = (double)group_allreduce<WAVE>(mine ? val[3] : 0.0f, FAdd());
                 const float vM = group_allreduce<WAVE>((mine && nq > 4) ? val[4] : __builtin_inff(), FMin());
                 if (lane == 0) {
                     sh.red[wave][0] = vS; sh.red[wave][1] = vP; sh.red[wave][2] = vQ;
