@@ -224,7 +224,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     }
     // nodes beyond the lookahead: a fresh geometric tail from the last corrected node
     {
-        const float last = __shfl(rnew_l, steps - 1, WAVE);      // all lanes take part
+        const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnew_l), steps - 1));
         if (lane < Ka && lane >= steps) rnew_l = last * exp2f(-(float)(lane - steps + 1));
     }
     float d_l = (has && lane < it_now) ? fabsf(rnew_l - rn) * __builtin_amdgcn_rcpf(rn) : 0.0f;
@@ -262,7 +262,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         trace[2 * lane] = err_l;
         trace[2 * lane + 1] = avg_l;
     }
-    const float rfin_w = __shfl(rnew_l, it_now - 1, WAVE);   // all lanes take part
+    const float rfin_w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnew_l), it_now - 1));
     if (lane == 0) {
         out.res_it = it_now;
         out.res_found = (found && round_ok) ? 1 : 0;
