@@ -1,26 +1,32 @@
-// Trajectory E-step for LARGE populations (train_rlvi.py:14-38; N from ~1e5 to 2e6 samples).
+// Trajectory E-step, slice-per-workgroup form (train_rlvi.py:14-38; N from 12 288 to 2 097 152:
+// the bench size, every dataset of the reference, the weak-scaling bench up to 8 x 65 536).
 //
 // Same mathematics as estep_traj.hip (rlvi_traj.h holds the shared recurrence): guessed nodes r'_k
-// of the whole fixed-point trajectory, per round the totals S(r'_k), dS/dr(r'_k), D(r'_k, r'_{k-1})
-// for all nodes, a first-order corrected scalar recurrence, repeat until the nodes stop moving.
-// What changes is the decomposition.  There a workgroup owns ONE node and a sixth of the samples,
-// which stops fitting registers near 1e5 samples; here every workgroup owns a small slice of the
-// samples (N/256, registers) and evaluates ALL live nodes on it:
+// of the whole fixed-point trajectory, per round the totals S(r'_k), dS/dr, -d2S/dr2 / 2 and
+// D(r'_k, r'_{k-1}) for all nodes, a corrected scalar recurrence, repeat until the nodes stop moving
+// (two rounds, warm or cold).  What changes is the decomposition.  There a workgroup owns ONE node
+// and a sixth of the samples, which stops fitting registers near 1e5 samples; here each of 256
+// workgroups owns a small slice of the samples (N/256, registers) and evaluates ALL live nodes on it:
 //   * eight nodes at a time: per-thread partials of {sum r e/(1+r e), sum e/(1+r e)^2, sum e^2/(1+r e)^3,
-//     sum d^2} (the recurrence corrects S to second order in the node error), then a
-//     transposing butterfly (v_permlane32_swap / v_permlane16_swap / row_ror:8 halve the number of
-//     live values at every step) leaves node (lane>>3)&7 of the chunk in each lane: 19 cross-lane
-//     operations per quantity for 8 nodes instead of 48;
+//     sum d^2}, sample pairs in packed fp32, then a transposing butterfly (v_permlane32_swap /
+//     v_permlane16_swap / row_ror:8 halve the number of live values at every step) leaves node
+//     (lane>>3)&7 of the chunk in each lane: 19 cross-lane operations per quantity for 8 nodes
+//     instead of 48;
 //   * only the nodes that matter are evaluated: Ke = (iterations of the previous call) + margin,
-//     grown when no stop index shows up among them;
+//     all of them when no stop index shows up among those;
 //   * the exchange has two stages: workgroup w publishes one 48-byte record per node (stage A);
 //     workgroup k < Ke gathers node k's 256 records, adds them in a fixed order and publishes the
 //     total (stage B); wave 0 of every workgroup reads the Ke totals (lane k = node k) and runs
-//     the recurrence.  Two ~2.5 us exchanges per round instead of K = 18-40 for the iteration.
-// Pads have e = 0 and drop out of every sum.  Per-thread and per-wave sums are fp32, cross-wave / cross-workgroup sums fp64 in a fixed
-// order, so every workgroup sees bit-identical totals and identical inputs + workspace state give
-// identical bits.  Protocol (sc1 stores / loads, self-tagged granules, parity buffers, tags from
-// the workspace base, wall-clock-bounded spins) as in rlvi_coop.h.
+//     the recurrence.  What a stage costs was decided by two things: a lane's write-through (sc1)
+//     stores leave one after the other, so every publish is ONE store per lane (four waves store
+//     S, S', Q, D of stage A; the 64 lanes of a wave the 8 x 8 granules of stage B); and 256
+//     workgroups polling the same 768 bytes serialise at the memory side, so the totals go out in
+//     8 replicas and a workgroup polls replica blockIdx % 8 (2.4-2.9 -> 0.8 us for that hop).
+// Pads have e = 0 and drop out of every sum.  Per-thread and per-wave sums are fp32; cross-wave and
+// cross-workgroup sums of S are fp64, in a fixed order, so every workgroup sees bit-identical totals
+// and identical inputs + workspace state give identical bits.  Protocol (sc1 stores / loads,
+// self-tagged granules, parity buffers, tags from the workspace base, wall-clock-bounded spins) as in
+// rlvi_coop.h.
 #include <stdlib.h>
 
 #include "rlvi_traj.h"
