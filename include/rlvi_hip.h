@@ -20,6 +20,10 @@
  *     One workspace must not be used by two streams at the same time.
  *   - device-side status: word 0 of the workspace is a sticky int32 status (0 = ok), bit flags
  *     RLVI_ST_*; out-of-range labels / indexes never touch memory, they set RLVI_ST_RANGE.
+ *     The Python plug-in reads it at every epoch end and raises on any flag.
+ *   - kernels whose workgroups wait for each other (E-step, threshold) size their grid from the
+ *     occupancy query of the current device, so that all of them are resident at once; every wait
+ *     is bounded in wall time (RLVI_SPIN_BOUND_MS, default 100) and sets RLVI_ST_TIMEOUT.
  */
 #ifndef RLVI_HIP_H
 #define RLVI_HIP_H
@@ -39,13 +43,22 @@ extern "C" {
 #define RLVI_E_WS     (-4) /* workspace too small / not initialised    */
 #define RLVI_E_LIMIT  (-5) /* size beyond what the kernels support     */
 
-#define RLVI_ST_RANGE   1  /* a label or index was out of range (row skipped)      */
-#define RLVI_ST_TIMEOUT 2  /* an inter-workgroup wait hit its bound (results invalid) */
+#define RLVI_ST_RANGE   1  /* a label or index was out of range: the row contributes nothing (zero gradient row,
+                              no residual written, not counted in loss / top-1)     */
+#define RLVI_ST_TIMEOUT 2  /* an inter-workgroup wait hit its bound (the workgroups of a cooperating launch were
+                              not all resident, e.g. beside another process's kernels): the launch left its
+                              outputs -- pi, threshold -- as they were                */
 #define RLVI_ST_NOCONV  4  /* the trajectory E-step did not reach its fixed point (results invalid) */
 #define RLVI_ST_SINGULAR 8 /* weighted least squares: Gram matrix not positive definite (theta = NaN) */
 
 int rlvi_abi_version(void);
 const char *rlvi_error_string(int code);
+
+/* Integer tuning / debug knob (same names as the RLVI_* environment variables, which it
+ * overrides); takes effect from the next launch.  Not needed for normal operation. */
+int rlvi_tune_set(const char *name, int value);
+/* Compute units of the current device as the launchers see them. */
+int rlvi_device_cus(void);
 
 /* Bytes of workspace needed for vectors up to max_n samples and batches up to max_b rows. */
 size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b);
@@ -53,6 +66,8 @@ size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b);
 int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream);
 /* Copy the sticky status word to *status_host (synchronises the stream). */
 int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream);
+/* Reset the sticky status word to 0 (nothing else: warm-start state and records are kept). */
+int rlvi_workspace_clear_status(void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * M-step over one mini-batch, forward + backward w.r.t. the logits, lagged pi.

@@ -20,9 +20,12 @@ _int = ctypes.c_int
 SIGNATURES = {
     "rlvi_abi_version": (_int, []),
     "rlvi_error_string": (ctypes.c_char_p, [_int]),
+    "rlvi_tune_set": (_int, [ctypes.c_char_p, _int]),
+    "rlvi_device_cus": (_int, []),
     "rlvi_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "rlvi_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
     "rlvi_workspace_status": (_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
+    "rlvi_workspace_clear_status": (_int, [_vp, _vp]),
     "rlvi_mstep_fwd_bwd_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                       _vp, _i64, _vp, _vp, _vp]),
     "rlvi_mstep_fwd_bwd_bf16": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
@@ -49,6 +52,21 @@ _lib = None
 
 class RlviError(RuntimeError):
     pass
+
+
+# device-side status flags (include/rlvi_hip.h)
+ST_RANGE, ST_TIMEOUT, ST_NOCONV, ST_SINGULAR = 1, 2, 4, 8
+_ST_TEXT = {
+    ST_RANGE: "a label or sample index was out of range (the reference raises an IndexError there)",
+    ST_TIMEOUT: "an inter-workgroup wait timed out: the cooperating workgroups were not all resident "
+                "(another process on this GPU?); pi / threshold were left as they were",
+    ST_NOCONV: "the E-step did not reach its fixed point (non-finite residuals?)",
+    ST_SINGULAR: "weighted least squares: the Gram matrix is not positive definite",
+}
+
+
+def status_message(status):
+    return "; ".join(t for b, t in _ST_TEXT.items() if status & b) or "ok"
 
 
 def load():

@@ -22,13 +22,32 @@ extern "C" size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b) {
     return ws_bytes_for(max_n, max_b);
 }
 
+namespace rlvi {
+__global__ void ws_header_kernel(WsHeader *hdr, unsigned long long spin_ticks, int clear_status) {
+    if (clear_status) hdr->status = 0;
+    else hdr->spin_ticks = spin_ticks;
+}
+}  // namespace rlvi
+
 extern "C" int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream) {
     if (!ws) return RLVI_E_NULL;
     if (((uintptr_t)ws & 255)) return RLVI_E_ALIGN;
     if (ws_bytes < WS_SCRATCH_OFF) return RLVI_E_WS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     // control words, exchange slots, warm-start state, M-step records (the WLS / scratch regions
     // behind them need no initial value)
-    return (int)hipMemsetAsync(ws, 0, WS_WLS_OFF, static_cast<hipStream_t>(stream));
+    hipError_t e = hipMemsetAsync(ws, 0, WS_WLS_OFF, st);
+    if (e != hipSuccess) return (int)e;
+    // bound of every inter-workgroup wait (RLVI_SPIN_BOUND_MS, default 100 ms), in 100 MHz ticks
+    const long long ms = tune_get("RLVI_SPIN_BOUND_MS", 100);
+    const unsigned long long ticks = (unsigned long long)(ms > 0 ? ms : 100) * 100000ull;
+    return launch(ws_header_kernel, dim3(1), dim3(1), 0, st, static_cast<WsHeader *>(ws), ticks, 0);
+}
+
+extern "C" int rlvi_workspace_clear_status(void *ws, void *stream) {
+    if (!ws) return RLVI_E_NULL;
+    return launch(ws_header_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream),
+                  static_cast<WsHeader *>(ws), 0ull, 1);
 }
 
 extern "C" int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream) {

@@ -1,0 +1,130 @@
+// Host-side device facts and tuning knobs shared by the launchers.
+//
+//   * device_info(): CU count of the current device, asked from the runtime once per device --
+//     the launch geometry of every kernel is derived from it, never from a constant.
+//   * coop_blocks(): how many workgroups of a kernel are provably co-resident (occupancy query
+//     x CU count, with the margin MI355X_MICROARCH.md prescribes where the API over-reports);
+//     every kernel whose workgroups wait for each other sizes its exchanging grid with it.
+//   * tune_get()/rlvi_tune_set(): integer knobs, default <- environment <- rlvi_tune_set().
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "rlvi_common.h"
+
+namespace rlvi {
+
+namespace {
+struct Knob {
+    char name[48];
+    int value;
+    bool from_set;
+};
+constexpr int MAX_KNOBS = 96;
+Knob g_knobs[MAX_KNOBS];
+int g_nknobs = 0;
+std::mutex g_mu;
+
+Knob *find(const char *name) {
+    for (int i = 0; i < g_nknobs; ++i)
+        if (strcmp(g_knobs[i].name, name) == 0) return &g_knobs[i];
+    return nullptr;
+}
+Knob *add(const char *name, int value, bool from_set) {
+    if (g_nknobs >= MAX_KNOBS || strlen(name) >= sizeof(g_knobs[0].name)) return nullptr;
+    Knob *k = &g_knobs[g_nknobs++];
+    strcpy(k->name, name);
+    k->value = value;
+    k->from_set = from_set;
+    return k;
+}
+
+constexpr int MAX_DEV = 64;
+DeviceInfo g_dev[MAX_DEV];
+bool g_dev_ok[MAX_DEV];
+}  // namespace
+
+int tune_get(const char *name, int dflt) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (Knob *k = find(name)) return k->value;
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    if (e) add(name, v, false);      // defaults are not cached: a later rlvi_tune_set still wins
+    return v;
+}
+
+const DeviceInfo &device_info() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_dev_ok[dev]) {
+        DeviceInfo d;
+        d.cus = NUM_CU_DEFAULT;
+        d.lds_per_cu = 160 * 1024;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            d.cus = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess &&
+            v > 0)
+            d.lds_per_cu = v;
+        g_dev[dev] = d;
+        g_dev_ok[dev] = true;
+    }
+    return g_dev[dev];
+}
+
+int coop_blocks_from_occupancy(int per_cu_api, int block_threads, int cus) {
+    // MI355X_MICROARCH.md, "Residency and cooperative launch": the occupancy API can answer one
+    // block per CU too many for 256-thread blocks with 81..112 SGPRs, and neither the plain nor the
+    // graph launch path checks.  One block per CU of margin where more than one is promised.
+    int per_cu = per_cu_api;
+    if (per_cu > 1 && block_threads <= 256) per_cu -= 1;
+    if (per_cu < 0) per_cu = 0;
+    long long n = (long long)per_cu * cus;
+    return n > (1 << 20) ? (1 << 20) : (int)n;
+}
+
+namespace {
+struct CapEntry { const void *kernel; int dev, block; size_t lds; int cap; };
+constexpr int MAX_CAPS = 256;
+CapEntry g_caps[MAX_CAPS];
+int g_ncaps = 0;
+}  // namespace
+
+int coop_cap_cached(const void *kernel, int block_threads, size_t dyn_lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (int i = 0; i < g_ncaps; ++i)
+            if (g_caps[i].kernel == kernel && g_caps[i].dev == dev && g_caps[i].block == block_threads &&
+                g_caps[i].lds == dyn_lds)
+                return g_caps[i].cap;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_lds) != hipSuccess)
+        per_cu = 0;
+    int cap = coop_blocks_from_occupancy(per_cu, block_threads, device_info().cus);
+    // debugging / tests: pretend the device admits fewer co-resident workgroups
+    const int forced = tune_get("RLVI_COOP_CAP", 0);
+    if (forced > 0 && forced < cap) cap = forced;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ncaps < MAX_CAPS && forced <= 0) g_caps[g_ncaps++] = CapEntry{kernel, dev, block_threads, dyn_lds, cap};
+    return cap;
+}
+
+}  // namespace rlvi
+
+extern "C" int rlvi_tune_set(const char *name, int value) {
+    if (!name) return RLVI_E_NULL;
+    std::lock_guard<std::mutex> lk(rlvi::g_mu);
+    if (rlvi::Knob *k = rlvi::find(name)) {
+        k->value = value;
+        k->from_set = true;
+        return 0;
+    }
+    return rlvi::add(name, value, true) ? 0 : RLVI_E_LIMIT;
+}
+
+extern "C" int rlvi_device_cus(void) { return rlvi::device_info().cus; }

@@ -4,7 +4,8 @@
 //   VAR_STD     update_weights          standard-learning/rlvi.py:8-20              (fp64)
 //   VAR_ONLINE  update_weights_rlvi     online-learning/main.py:45-58               (fp64)
 //
-// Each of G workgroups (1024 threads, one per CU) keeps E elements per thread of e_i=exp(-l_i)
+// Each of G workgroups (256 or 1024 threads; G is checked against what the occupancy query says is
+// co-resident on this device) keeps E elements per thread of e_i=exp(-l_i)
 // and pi_i in registers for the whole fixed point; per iteration the only traffic is the
 // 32-byte record exchange of rlvi_coop.h ({sum pi, sum (pi'-pi)^2} as doubles).  Sums are
 // accumulated in fp64 in a fixed order, so the result is deterministic and every workgroup takes
@@ -17,11 +18,7 @@ namespace rlvi {
 
 enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
 
-// estep_traj.hip: the trajectory solver of the deep variant (returns 0 when not applicable)
-int try_launch_estep_traj(float *res, float *wts, int64_t N, float tol, int maxiter,
-                          int32_t *out_iters, float *trace, void *ws, hipStream_t st,
-                          float *mstep_out, double mstep_scale, int *rc);
-// estep_trajb.hip: the same solver decomposed for large populations
+// estep_trajb.hip: the trajectory solver of the deep variant (returns 0 when not applicable)
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                            float *mstep_out, double mstep_scale, int *rc);
@@ -160,13 +157,15 @@ __global__ __launch_bounds__(ESTEP_BLOCK) void estep_kernel(F *__restrict__ res,
             mx = (F)a;
         }
         if (VAR == VAR_ONLINE) mx = mx * (F)N;        // new /= max(new)*len(new)  (main.py:57)
+        // (a wait that timed out -- RLVI_ST_TIMEOUT -- leaves the output as it was: the host raises
+        //  on the status, it never hands out sums of a partial population)
 #pragma unroll
         for (int j = 0; j < E; ++j)
-            if (ok_(j)) wts[i0 + j * gstride] = w[j] / mx;   // weights.div_(max)   (:38)
+            if (ok_(j) && !co.dead) wts[i0 + j * gstride] = w[j] / mx;   // weights.div_(max)   (:38)
     } else {
 #pragma unroll
         for (int j = 0; j < E; ++j)
-            if (ok_(j)) wts[i0 + j * gstride] = w[j];
+            if (ok_(j) && !co.dead) wts[i0 + j * gstride] = w[j];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (out_iters != nullptr) *out_iters = it;
@@ -188,32 +187,33 @@ static int launch_estep(F *res, F *wts, int64_t N, F tol, int maxiter, int32_t *
         if (try_launch_estep_trajb(res, wts, N, tol, maxiter, out_iters, trace, ws, st, mstep_out,
                                    mstep_scale, &rc))
             return rc;
-        if (try_launch_estep_traj(res, wts, N, tol, maxiter, out_iters, trace, ws, st, mstep_out,
-                                  mstep_scale, &rc))
-            return rc;
     }
-    static const int force_e = getenv("RLVI_ESTEP_E") ? atoi(getenv("RLVI_ESTEP_E")) : 0;
-    static const int force_b = getenv("RLVI_ESTEP_BLOCK") ? atoi(getenv("RLVI_ESTEP_BLOCK")) : 0;
+    const int force_e = tune_get("RLVI_ESTEP_E", 0);
+    const int force_b = tune_get("RLVI_ESTEP_BLOCK", 0);
     auto groups = [&](int64_t blk, int e) { return (N + blk * e - 1) / (blk * e); };
-#define RLVI_LAUNCH(E_, B_)                                                                      \
+    const int extra = mstep_out != nullptr ? 1 : 0;
+    // every geometry is admitted only if all its workgroups (+ the epoch-end reduction workgroup)
+    // are provably co-resident on this device (occupancy query x CUs) and fit the exchange slots
+#define RLVI_LAUNCH(E_, B_, LIM_)                                                                \
     do {                                                                                         \
-        hipLaunchKernelGGL((estep_kernel<F, VAR, E_, B_>),                                       \
-                           dim3((unsigned)groups(B_, E_) + (mstep_out != nullptr ? 1u : 0u)),    \
-                           dim3(B_), 0, st, res, wts, N, tol, maxiter, out_iters, trace, ws,     \
-                           mstep_out, mstep_scale);                                              \
-        return (int)hipGetLastError();                                                           \
+        auto kern = estep_kernel<F, VAR, E_, B_>;                                                \
+        const int64_t g_ = groups(B_, E_);                                                       \
+        int cap_ = coop_cap(kern, B_) - extra;                                                   \
+        if (cap_ > (LIM_)) cap_ = (LIM_);                                                        \
+        if (g_ <= cap_)                                                                          \
+            return launch(kern, dim3((unsigned)(g_ + extra)), dim3(B_), 0, st, res, wts, N, tol, \
+                          maxiter, out_iters, trace, ws, mstep_out, mstep_scale);                \
     } while (0)
-    const int lim = MAX_COOP_WG - 1;    // one CU stays free for the epoch-end reduction workgroup
+    const int lim = MAX_COOP_WG - 1;    // exchange slots, one kept for the epoch-end reduction workgroup
     if (force_b == 256 || force_b == 0) {
-        if ((force_e == 8 || !force_e) && groups(256, 8) <= lim / 4) RLVI_LAUNCH(8, 256);
-        if ((force_e == 16 || !force_e) && groups(256, 16) <= lim / 4) RLVI_LAUNCH(16, 256);
-        if (force_e == 32 && sizeof(F) == 4 && groups(256, 32) <= lim) RLVI_LAUNCH(16, 256);
+        if (force_e == 8 || !force_e) RLVI_LAUNCH(8, 256, lim / 4);
+        if (force_e == 16 || !force_e) RLVI_LAUNCH(16, 256, lim / 4);
     }
-    if (force_e == 4 && groups(1024, 4) <= lim) RLVI_LAUNCH(4, 1024);
-    if (groups(1024, 8) <= lim) RLVI_LAUNCH(8, 1024);
-    if (groups(1024, 16) <= lim) RLVI_LAUNCH(16, 1024);
+    if (force_e == 4) RLVI_LAUNCH(4, 1024, lim);
+    RLVI_LAUNCH(8, 1024, lim);
+    RLVI_LAUNCH(16, 1024, lim);
     if constexpr (sizeof(F) == 4) {
-        if (groups(1024, 32) <= lim) RLVI_LAUNCH(32, 1024);
+        RLVI_LAUNCH(32, 1024, lim);
     }
 #undef RLVI_LAUNCH
     return RLVI_E_LIMIT;

@@ -1,12 +1,10 @@
-// Trajectory E-step, slice-per-workgroup form (train_rlvi.py:14-38; N from 12 288 to 2 097 152:
-// the bench size, every dataset of the reference, the weak-scaling bench up to 8 x 65 536).
+// Trajectory E-step (train_rlvi.py:14-38; N from 4096 to 2 097 152: the bench size, every dataset
+// of the reference, the weak-scaling bench up to 8 x 65 536).
 //
-// Same mathematics as estep_traj.hip (rlvi_traj.h holds the shared recurrence): guessed nodes r'_k
-// of the whole fixed-point trajectory, per round the totals S(r'_k), dS/dr, -d2S/dr2 / 2 and
-// D(r'_k, r'_{k-1}) for all nodes, a corrected scalar recurrence, repeat until the nodes stop moving
-// (two rounds, warm or cold).  What changes is the decomposition.  There a workgroup owns ONE node
-// and a sixth of the samples, which stops fitting registers near 1e5 samples; here each of 256
-// workgroups owns a small slice of the samples (N/256, registers) and evaluates ALL live nodes on it:
+// Guessed nodes r'_k of the whole fixed-point trajectory (rlvi_traj.h holds the recurrence), per
+// round the totals S(r'_k), dS/dr, -d2S/dr2 / 2 and D(r'_k, r'_{k-1}) for all nodes, a corrected
+// scalar recurrence, repeat until the nodes stop moving (two rounds, warm or cold).  Each of up to
+// 256 workgroups owns a small slice of the samples (N/256, registers) and evaluates ALL live nodes on it:
 //   * eight nodes at a time: per-thread partials of {sum r e/(1+r e), sum e/(1+r e)^2, sum e^2/(1+r e)^3,
 //     sum d^2}, sample pairs in packed fp32, then a transposing butterfly (v_permlane32_swap /
 //     v_permlane16_swap / row_ror:8 halve the number of live values at every step) leaves node
@@ -43,7 +41,7 @@ typedef unsigned int tb_vu4 __attribute__((ext_vector_type(4)));
 #endif
 // 256 exchanging workgroups (+1 for the epoch-end reduction, which then shares a CU): at the bench
 // size a slice is exactly one sample per thread (32.6 us per step against 33.9 with 240).
-constexpr int TB_G = RLVI_TB_G;
+constexpr int TB_G = RLVI_TB_G;      // exchanging workgroups at most (= exchange slots per node)
 constexpr int TB_CHUNK = 8;
 constexpr int TB_NV = 5;             // values of a record: {S, P, Q, D, min}
 constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
@@ -118,11 +116,13 @@ template <int E, int TB_BLOCK>
 __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
-    float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg) {
+    float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G) {
+    // G <= TB_G exchanging workgroups (what is provably co-resident on this device), block G = the
+    // epoch-end reduction
     int dbgi = 0;
 #define TB_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
     TB_STAMP();
-    if ((int)blockIdx.x == TB_G) {   // epoch end: reduce + clear the M-step records (own CU)
+    if ((int)blockIdx.x == G) {   // epoch end: reduce + clear the M-step records (own CU)
         double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF);
         reduce_partials(part, MSTEP_MAX_BLOCKS, mstep_scale, mstep_out, true, TB_BLOCK);
         return;
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     TrajState *state = reinterpret_cast<TrajState *>(wsb + WS_TRAJ_OFF);
     uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned long long spin_ticks = spin_bound(hdr);
     int xstep = 0;
     bool dead = false;
 
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     const int lane = tid & (WAVE - 1);
     const int wave = tid / WAVE;
     const int b = (int)blockIdx.x;
-    const int64_t L = (N + TB_G - 1) / TB_G;
-    const int64_t lo = (int64_t)b * L;
+    const int64_t L = (N + G - 1) / G;
+    const int64_t lo = (int64_t)b * L < N ? (int64_t)b * L : N;
     const int64_t hi = lo + L < N ? lo + L : N;
 
     // ---- warm-start state (read early: its latency hides behind the slice loads)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         if (b < Ke) {
             if (wave < TB_PER && !dead) {
                 const int w = wave * WAVE + lane;
-                const bool mine = w < TB_G;
+                const bool mine = w < G;
                 gu64 *p = A + ((size_t)b * MAX_COOP_WG + (mine ? w : 0)) * XCHG3_GRANULES;
                 const unsigned long long t0 = wall_clock64();
                 bool timeout = false;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                 for (unsigned spin = 0;; ++spin) {
                     const bool ok = load_rec(p, tag, nq, val) || !mine;
                     if (__all(ok)) break;
-                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) {
                         timeout = true;
                         break;
                     }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                 for (unsigned spin = 0;; ++spin) {
                     const bool ok = load_rec(p, tag, nq, val) || !mine;
                     if (__all(ok)) break;
-                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) {
                         timeout = true;
                         break;
                     }
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     }
     // every round makes at least one more node exact; anything else is a bug or a non-finite
     // input: report it instead of returning silently wrong posteriors
-    if (!accepted && tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
+    if (!accepted && !dead && tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
 
     // ---- weights = pi / max(pi); max is attained at e = 1 (the min-residual sample) (:38):
     // same expression for f_max as per element and a true division, so that sample is exactly 1.0
@@ -384,11 +385,15 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     // (a solve that did not converge -- a non-finite residual -- poisons every weight, as the
     //  reference's min / mean over a vector with a NaN does)
     const float pmax = accepted ? tmax * __builtin_amdgcn_rcpf(1.0f + tmax) : __builtin_nanf("");
+    // a wait that timed out (RLVI_ST_TIMEOUT: the workgroups were not all resident) leaves the
+    // caller's pi as it was -- the host raises on the status; it never hands out garbage
+    if (!dead) {
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int64_t i = lo + tid + (int64_t)j * TB_BLOCK;
-        const float t = r_fin * ev[j];
-        if (i < hi) wts[i] = (t * __builtin_amdgcn_rcpf(1.0f + t)) / pmax;
+        for (int j = 0; j < E; ++j) {
+            const int64_t i = lo + tid + (int64_t)j * TB_BLOCK;
+            const float t = r_fin * ev[j];
+            if (i < hi) wts[i] = (t * __builtin_amdgcn_rcpf(1.0f + t)) / pmax;
+        }
     }
     TB_STAMP();   // final stores issued
     if (dbg != nullptr && b == 0 && tid == 0) dbg[63] = (unsigned long long)dbgi;
@@ -407,32 +412,44 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
 }
 
 // Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if not applicable.
-// Measured crossover against the node-per-workgroup kernel (whole step, hipGraph): 21.8 vs 22.9 us
-// at N = 4096, 21.6 vs 22.1 us at 8192, 25.2 vs 24.0 us at 16 384, 42.1 vs 28.9 us at 65 536.
+// (Round 1 had a node-per-workgroup form for 4096 <= N < 12 288 -- 240 workgroups of 1024 threads,
+//  0.5 us ahead at N = 8192; it needed a whole CU per workgroup to be free and was retired.)
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                            float *mstep_out, double mstep_scale, int *rc) {
-    static const int mode = getenv("RLVI_ESTEP_TRAJB") ? atoi(getenv("RLVI_ESTEP_TRAJB")) : 1;
-    static const int64_t nmin = getenv("RLVI_ESTEP_TRAJB_NMIN") ? atoll(getenv("RLVI_ESTEP_TRAJB_NMIN")) : 12288;
-    if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin || N < TB_G) return 0;
-    const int64_t L = (N + TB_G - 1) / TB_G;
-    if (L > 8192) return 0;
-    const unsigned grid = (unsigned)TB_G + (mstep_out != nullptr ? 1u : 0u);
-    static const int debug = getenv("RLVI_TJ_DEBUG") ? atoi(getenv("RLVI_TJ_DEBUG")) : 0;
+    const int mode = tune_get("RLVI_ESTEP_TRAJB", 1);
+    const int64_t nmin = tune_get("RLVI_ESTEP_TRAJB_NMIN", 4096);
+    if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin) return 0;
+    const int debug = tune_get("RLVI_TJ_DEBUG", 0);
     // 256 threads measured 2-3 us per call ahead up to N = 262 144, level at 524 288, 1 us behind
     // from 1e6 on (whole step / eager call, hipGraph): 512 threads only for slices beyond 4096
-    static const int blk = getenv("RLVI_TB_BLOCK") ? atoi(getenv("RLVI_TB_BLOCK")) : 0;
+    const int blk = tune_get("RLVI_TB_BLOCK", 0);
     unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+    const int extra = mstep_out != nullptr ? 1 : 0;
+    // The exchanging workgroups wait for each other, so all of them (and the reduction workgroup)
+    // must be resident at once: G = min(TB_G, what the occupancy query promises for this kernel
+    // on this device, less the reduction workgroup).  Too few for the slice to fit: not applicable
+    // (the iterative kernel takes over).
+    int launched = 0;
 #define RLVI_TB(E_, B_)                                                                           \
-    hipLaunchKernelGGL((estep_trajb_kernel<E_, B_>), dim3(grid), dim3(B_), 0, st, res, wts, N,    \
-                       tol, maxiter, out_iters, trace, ws, mstep_out, mstep_scale, dbg)
+    do {                                                                                          \
+        auto kern = estep_trajb_kernel<E_, B_>;                                                   \
+        int G = coop_cap(kern, B_) - extra;                                                       \
+        if (G > TB_G) G = TB_G;                                                                   \
+        if (G >= TJ_MAXK && (N + G - 1) / G <= (int64_t)(E_) * (B_)) {   /* node k is reduced by workgroup k */                                  \
+            *rc = launch(kern, dim3((unsigned)(G + extra)), dim3(B_), 0, st, res, wts, N, tol, maxiter, \
+                         out_iters, trace, ws, mstep_out, mstep_scale, dbg, G);                   \
+            launched = 1;                                                                         \
+        }                                                                                         \
+    } while (0)
+    const int64_t L = (N + TB_G - 1) / TB_G;      // slice at the full width
     if (blk == 512 || (blk == 0 && L > 256 * 16)) {
         if (L <= 512 * 2) RLVI_TB(2, 512);
         else if (L <= 512 * 4) RLVI_TB(4, 512);
         else if (L <= 512 * 6) RLVI_TB(6, 512);
         else if (L <= 512 * 8) RLVI_TB(8, 512);
         else if (L <= 512 * 12) RLVI_TB(12, 512);
-        else RLVI_TB(16, 512);
+        else if (L <= 512 * 16) RLVI_TB(16, 512);
     } else {
         if (L <= 256 * 1) RLVI_TB(1, 256);
         else if (L <= 256 * 2) RLVI_TB(2, 256);
@@ -444,11 +461,15 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
         else if (L <= 256 * 12) RLVI_TB(12, 256);
         else if (L <= 256 * 16) RLVI_TB(16, 256);
         else if (L <= 256 * 24) RLVI_TB(24, 256);
-        else RLVI_TB(32, 256);
+        else if (L <= 256 * 32) RLVI_TB(32, 256);
+    }
+    if (!launched) {
+        // fewer co-resident workgroups than TB_G: the fattest instantiations take longer slices
+        RLVI_TB(16, 512);
+        if (!launched) RLVI_TB(32, 256);
     }
 #undef RLVI_TB
-    *rc = (int)hipGetLastError();
-    return 1;
+    return launched;
 }
 
 }  // namespace rlvi

@@ -13,6 +13,8 @@
 // reductions (max, sum-exp, arg-max) are butterfly shuffles inside the lane group.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "rlvi_common.h"
 
 namespace rlvi {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
     float *__restrict__ residuals, int64_t N, int64_t B, int C, int kact, float inv_scale,
     T *__restrict__ grad, int64_t ldg, double *__restrict__ part, int32_t *__restrict__ status,
-    int accum, double inv_rows100) {
+    int accum, double inv_rows100, int64_t first_row) {
     constexpr int R = WAVE / G;  // rows per wave
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
             VecIO<T, V>::load_stream(zrow + (live[k] ? col : g * V), v[k]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        ix = idx != nullptr ? ix : rr;                // idx == NULL: identity (in-batch E+M)
+        ix = idx != nullptr ? ix : first_row + rr;    // idx == NULL: identity (in-batch E+M), counted from the batch start
         bool row_ok = valid;
         if (y64 < 0 || y64 >= C) { y64 = 0; bad = bad || valid; row_ok = false; }
         if (ix < 0 || ix >= N) { ix = 0; bad = bad || valid; row_ok = false; }
@@ -508,15 +510,301 @@ __global__ __launch_bounds__(MSTEP_THREADS, RLVI_MSTEP_MINWAVES) void mstep_tile
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave-tile form (dense rows): every WAVE streams its own tiles of R = 64/G rows through its own
+// slice of LDS -- no workgroup barrier anywhere, and the hot loop is straight-line code:
+//   A  label / index (asm loads the compiler does not count), then the tile global -> LDS by
+//      LDS-DMA (global_load_lds_dwordx4: flat, 16 B per lane, 1 KiB per wave instruction, no
+//      staging registers); the wait for "all but the DMA pieces" hands over label / index while
+//      the tile is still in flight, so the dependent pi gather flies beside the tile
+//   B  G-lane groups own the rows as in the other forms.  A lane's slots past the end of the row
+//      alias the row's LAST vector: they read what its owner reads (harmless for the maximum),
+//      are masked out of the sum, and their in-place gradient write repeats the owner's value --
+//      no execution-mask juggling.  The -onehot term is one LDS read-modify-write per row (all
+//      lanes of the group write the same value)
+//   C  flat nontemporal 16-B/lane stores LDS -> grad
+// Only full tiles; the launcher hands the B mod R trailing rows to the register-row kernel.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+// RLVI_MSTEP_DMA=1: stage the tile by LDS-DMA (global_load_lds_dwordx4) instead of nontemporal
+// register loads + ds_write.  Measured slower at 65 536 x 100 (12.3 against 10.4 us): a CU accepts
+// DMA pieces only about as fast as they return, so the last workgroup of a CU issues its reads 3 us
+// after the first, while register loads of all 16 waves of a CU are in flight at once.
+#ifndef RLVI_MSTEP_DMA
+#define RLVI_MSTEP_DMA 0
+#endif
+#ifndef RLVI_MSTEP_EARLY_PI
+#define RLVI_MSTEP_EARLY_PI 0
+#endif
+#ifndef RLVI_MSTEP_DMA_AUX
+#define RLVI_MSTEP_DMA_AUX 2      // cache policy of the tile DMA: 2 = nt (read once)
+#endif
+// -DRLVI_MSTEP_STAMPS: diagnostic build, every wave leaves wall-clock stamps (100 MHz) of its first
+// tile's phases in the workspace scratch (tools/mstep_stamps.py); never in the product library.
+#ifdef RLVI_MSTEP_STAMPS
+#define RLVI_STAMP(k) do { if (lane == 0 && first_tile) stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RLVI_STAMP(k) do { } while (0)
+#endif
+#ifndef RLVI_MSTEP_WAVE_MINW
+#define RLVI_MSTEP_WAVE_MINW 4    // waves per SIMD the register allocation must allow (LDS allows 5)
+#endif
+
+struct FMaxF { __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); } };
+
+// EXACT: the host guarantees ceil(ceil(C/V)/G) == KMAX, so only a lane's LAST slot can lie past
+// the end of the row and (for 16-byte vectors) only the last DMA / store piece can be partial.
+template <typename T, int V, int G, int KMAX, int WPB, bool EXACT>
+__global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_kernel(
+    const T *__restrict__ logits, const int64_t *__restrict__ labels,
+    const int64_t *__restrict__ idx, const float *__restrict__ weights,
+    float *__restrict__ residuals, int64_t N, int64_t nfull, int C, float inv_scale,
+    T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status, int accum,
+    double inv_rows100) {
+    constexpr int R = WAVE / G;                                   // rows per wave tile
+    constexpr int VB = V * (int)sizeof(T);                        // bytes of a lane vector
+    constexpr int NI = (KMAX * VB + 15) / 16;                     // 1-KiB pieces per tile (max)
+    constexpr int WTILE = NI * 1024;                              // LDS bytes per wave
+    constexpr bool EXACT16 = EXACT && VB == 16;                   // then pieces 0..NI-2 are full
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int g = lane & (G - 1);
+    const int sub = lane / G;
+    const int nv = C / V;                                         // vectors per row (V divides C)
+    const int nchunk = (R * C * (int)sizeof(T)) >> 4;            // 16-byte chunks of a tile
+    char *wtile = smem + (size_t)wave * WTILE;
+    vu4 *tile16 = reinterpret_cast<vu4 *>(wtile);
+    const int64_t tstride = (int64_t)gridDim.x * WPB;
+#ifdef RLVI_MSTEP_STAMPS
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(
+        reinterpret_cast<char *>(status) + WS_SCRATCH_OFF) + ((size_t)blockIdx.x * WPB + wave) * 16;
+    bool first_tile = true;
+    RLVI_STAMP(0);
+    if (lane == 0) {
+        stamps[8] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+        stamps[9] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+    }
+#endif
+
+    // loop-invariant per-lane geometry
+    unsigned dma_off[NI];                                         // byte offset of this lane's chunk of piece i
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int c = i * WAVE + lane;
+        if (!(EXACT16 && i < NI - 1)) c = c < nchunk ? c : nchunk - 1;   // past the tile: re-read its last chunk
+        dma_off[i] = (unsigned)c * 16u;
+    }
+    int slot_off[KMAX];                                           // LDS byte offset of slot k inside the slice
+    bool live[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int vec = k * G + g;
+        live[k] = (EXACT && k < KMAX - 1) || vec < nv;
+        slot_off[k] = (sub * C + (live[k] ? vec : nv - 1) * V) * (int)sizeof(T);
+    }
+    const int row_off = sub * C * (int)sizeof(T);
+    const int64_t *idxp = idx != nullptr ? idx : labels;
+    const unsigned sub8 = (unsigned)sub * 8u;
+
+    float acc = 0.0f, hits = 0.0f;
+    bool bad = false;
+
+    for (int64_t t = (int64_t)blockIdx.x * WPB + wave; t < nfull; t += tstride) {
+        const int64_t row_base = t * R;
+        // ---- A
+        const char *src = reinterpret_cast<const char *>(logits + row_base * C);
+        int64_t y64, ix;
+        bool okrow = true;
+        float pi;
+#if RLVI_MSTEP_DMA
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(y64) : "v"(sub8), "s"(labels + row_base) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ix) : "v"(sub8), "s"(idxp + row_base) : "memory");
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(src + dma_off[i]), (lptr_t *)(wtile + i * 1024), 16, 0,
+                                             RLVI_MSTEP_DMA_AUX);
+        RLVI_STAMP(1);
+        // vmcnt(NI): everything older than the NI DMA pieces (= label and index) has returned
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(y64), "+v"(ix) : "n"(NI) : "memory");
+        ix = idx != nullptr ? ix : row_base + sub;
+        if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
+        if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
+        pi = weights != nullptr ? weights[ix] : 1.0f;             // flies beside the tile
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pi) : : "memory");   // tile and pi landed
+#else
+        // label and index first (they return ahead of the tile: loads return in order), the tile's
+        // NI chunks per lane behind them
+        y64 = *reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(labels + row_base) + sub8);
+        ix = *reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(idxp + row_base) + sub8);
+        vu4 stg[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            stg[i] = __builtin_nontemporal_load(reinterpret_cast<const vu4 *>(src + dma_off[i]));
+        RLVI_STAMP(1);
+        ix = idx != nullptr ? ix : row_base + sub;
+        if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
+        if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
+#if RLVI_MSTEP_EARLY_PI
+        pi = weights != nullptr ? weights[ix] : 1.0f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) tile16[i * WAVE + lane] = stg[i];
+#else
+        // the tile first, the gather once it has landed: 64 K random 4-byte reads queued beside the
+        // streaming reads cost the launch 1 us (12.0 against 11.0 us at 65 536 x 100); issued here they
+        // are L2 hits on a quiet queue and fly during the first half of phase B
+#pragma unroll
+        for (int i = 0; i < NI; ++i) tile16[i * WAVE + lane] = stg[i];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(y64), "+v"(ix) : : "memory");
+        pi = weights != nullptr ? weights[ix] : 1.0f;
+#endif
+#endif
+        RLVI_STAMP(2);
+        bad = bad || !okrow;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- B
+        const int y = (int)y64;
+        char *zrow = wtile + row_off;
+        float zy;
+        {
+            float tt[1];
+            VecIO<T, 1>::load(reinterpret_cast<T *>(zrow) + y, tt);
+            zy = tt[0];
+        }
+        float v[KMAX][V];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) VecIO<T, V>::load(reinterpret_cast<T *>(wtile + slot_off[k]), v[k]);
+        float m = v[0][0];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int j = 0; j < V; ++j) m = __builtin_fmaxf(m, v[k][j]);
+        m = group_allreduce<G>(m, FMaxF());
+#ifdef RLVI_MSTEP_STAMPS
+        asm volatile("" : "+v"(m));
+        RLVI_STAMP(3);
+#endif
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float e = mexp(v[k][j] - m);
+                v[k][j] = e;
+                s += live[k] ? e : 0.0f;
+            }
+        s = group_sum<G>(s);
+#ifdef RLVI_MSTEP_STAMPS
+        asm volatile("" : "+v"(s));
+        RLVI_STAMP(4);
+#endif
+        // s is in [1, C]: v_log_f32 needs no range fix-up
+        const float li = __builtin_amdgcn_logf(s) * 0.69314718055994530942f - (zy - m);
+        // top-1: the label is a hit when it is the FIRST column that attains the row maximum
+        // (torch.max order, deep-learning/utils.py:58).  Two exact maxima put at least 2.0 into
+        // the sum, so the exact check runs only for waves that hold such a row.
+        pi = okrow ? pi : 0.0f;                                   // a rejected row gets a zero gradient
+        bool hit = zy == m;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit && s >= 2.0f) != 0, 0)) {
+            int earlier = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                float z[V];
+                asm volatile("" ::: "memory");                     // re-read, do not keep the first copy live
+                VecIO<T, V>::load(reinterpret_cast<T *>(wtile + slot_off[k]), z);
+                const int col = (k * G + g) * V;
+#pragma unroll
+                for (int j = 0; j < V; ++j) earlier += (live[k] && z[j] == m && col + j < y) ? 1 : 0;
+            }
+            earlier = group_allreduce<G>(earlier, FAdd());
+            hit = hit && earlier == 0;
+        }
+        if (grad != nullptr) {
+            const float gs = pi * inv_scale;
+            const float inv_s = gs * __builtin_amdgcn_rcpf(s);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    o[j] = v[k][j] * inv_s;
+                    if (sizeof(T) != 4) {
+                        const int colc = (live[k] ? (k * G + g) : nv - 1) * V + j;
+                        if (colc == y) o[j] -= gs;
+                    }
+                }
+                VecIO<T, V>::store(reinterpret_cast<T *>(wtile + slot_off[k]), o);   // in place
+            }
+            if (sizeof(T) == 4) {
+                // -onehot term: one read-modify-write of the label entry, ordered behind this wave's
+                // vector stores (LDS operations of a wave complete in order); the lanes of a group
+                // all write the same value
+                float *zf = reinterpret_cast<float *>(zrow);
+                zf[y] = zf[y] - gs;
+            }
+        }
+        if (g == 0 && okrow && residuals != nullptr) residuals[ix] = li;
+        acc += okrow ? li * pi : 0.0f;
+        hits += (hit && okrow) ? 1.0f : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        RLVI_STAMP(5);
+
+        // ---- C: flat store of the gradient tile
+#ifndef RLVI_MSTEP_NT_STORE
+#define RLVI_MSTEP_NT_STORE 1
+#endif
+#if RLVI_MSTEP_NT_STORE
+#define RLVI_TILE_STORE(val, ptr) __builtin_nontemporal_store(val, ptr)
+#else
+#define RLVI_TILE_STORE(val, ptr) (*(ptr) = (val))
+#endif
+        if (grad != nullptr) {
+            char *gdst = reinterpret_cast<char *>(grad + row_base * C);
+            vu4 st[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) st[i] = tile16[i * WAVE + lane];      // inside this wave's slice
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (EXACT16 && i < NI - 1) {
+                    RLVI_TILE_STORE(st[i], reinterpret_cast<vu4 *>(gdst + dma_off[i]));
+                } else if ((i + 1) * WAVE <= nchunk) {
+                    RLVI_TILE_STORE(st[i], reinterpret_cast<vu4 *>(gdst + dma_off[i]));
+                } else if (i * WAVE + lane < nchunk) {
+                    RLVI_TILE_STORE(st[i], reinterpret_cast<vu4 *>(gdst + dma_off[i]));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef RLVI_MSTEP_STAMPS
+        RLVI_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RLVI_STAMP(7);
+        first_tile = false;
+#endif
+    }
+
+    // every lane of a row's group carried the row's sums: count each row once
+    double a = wave_sum((double)(g == 0 ? acc : 0.0f));
+    double h = wave_sum((double)(g == 0 ? hits : 0.0f));
+    __shared__ double sh[2 * WPB];
+    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = h; }
+    if (bad) atomicOr(status, RLVI_ST_RANGE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, th = 0.0;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
+        write_partial(part, ta, th, inv_scale, inv_rows100, accum);
+    }
+}
+
 __global__ __launch_bounds__(256) void mstep_finalize_kernel(double *__restrict__ part, int nblocks,
                                                              double scale, float *__restrict__ out,
                                                              int clear) {
     reduce_partials(part, nblocks, scale, out, clear != 0, 256);
-}
-
-static int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
 }
 
 template <typename T, int V, int G, int KMAX>
@@ -526,45 +814,73 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
                         hipStream_t st) {
     constexpr int R = WAVE / G;
     constexpr int TR = MSTEP_THREADS / G;
-    static const int max_blocks = env_int("RLVI_MSTEP_BLOCKS", MSTEP_MAX_BLOCKS);
-    static const int use_tile = env_int("RLVI_MSTEP_TILE", 1);
+    constexpr int WPB = 4;                          // waves per workgroup of the wave-tile form
+    const int cus = device_info().cus;
+    // form: 2 = wave tiles (LDS-DMA, no barriers), 1 = workgroup tiles, 0 = register rows
+    const int form = tune_get("RLVI_MSTEP_FORM", 2);
     char *base = static_cast<char *>(ws);
     double *part = reinterpret_cast<double *>(base + WS_PART_OFF);
     int32_t *status = reinterpret_cast<int32_t *>(base);
     const int accum = out == nullptr ? 1 : 0;       // no `out`: accumulate for rlvi_epoch_end_f32
     const double inv_rows100 = 100.0 / (double)B;
+    const bool flat16 = ld == C && (grad == nullptr || ldg == C) &&
+                        ((uintptr_t)logits % 16) == 0 && ((uintptr_t)grad % 16) == 0;
+    const size_t wtile_bytes = (size_t)R * C * sizeof(T);
     const size_t tile_bytes = (size_t)TR * C * sizeof(T);
-    const bool dense = ld == C && (grad == nullptr || ldg == C) && tile_bytes % 16 == 0 &&
-                       ((uintptr_t)logits % 16) == 0 && ((uintptr_t)grad % 16) == 0 &&
-                       (tile_bytes + 15) / 16 <= (size_t)((KMAX * V * sizeof(T) + 15) / 16) * MSTEP_THREADS;
+    constexpr size_t SKB = (size_t)((KMAX * V * sizeof(T) + 15) / 16);
+    const bool dense_wave = flat16 && wtile_bytes % 16 == 0 && wtile_bytes / 16 <= SKB * WAVE;
+    const bool dense_tile = flat16 && tile_bytes % 16 == 0 && (tile_bytes + 15) / 16 <= SKB * MSTEP_THREADS;
     int64_t nb;
-    if (dense && use_tile) {
-        // three workgroups per CU, looping over the tiles: measured best at 1024 tiles (11.7 us
-        // against 12.1 us for one tile per workgroup and 13.3-13.8 us for 2 or 2.5 per CU) -- the
-        // workgroups that take a second tile read it while the others are already writing
+    int rc;
+    const int64_t nfull = B / R;
+    if (dense_wave && form >= 2 && nfull > 0) {
+        // `wpc` waves per CU stride over the R-row tiles (one tile each at the bench size)
+        const int wpc = tune_get("RLVI_MSTEP_WPC", 16);
+        nb = (nfull + WPB - 1) / WPB;
+        int64_t cap = ((int64_t)wpc * cus + WPB - 1) / WPB;
+        if (cap > MSTEP_MAX_BLOCKS) cap = MSTEP_MAX_BLOCKS;
+        if (nb > cap) nb = cap;
+        const size_t lds = (size_t)WPB * SKB * 1024;
+        if (kact == KMAX)
+            rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, true>, dim3((unsigned)nb), dim3(WPB * WAVE),
+                        lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
+                        part, status, accum, inv_rows100);
+        else
+            rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, false>, dim3((unsigned)nb), dim3(WPB * WAVE),
+                        lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
+                        part, status, accum, inv_rows100);
+        const int64_t done = nfull * R;
+        if (rc == 0 && done < B) {
+            // the B mod R trailing rows: one workgroup of the register-row kernel, adding to record 0
+            rc = launch(mstep_kernel<T, V, G, KMAX>, dim3(1), dim3(MSTEP_THREADS), 0, st,
+                        logits + done * ld, ld, labels + done, idx != nullptr ? idx + done : idx, weights,
+                        residuals, N, B - done, C, kact, inv_scale, grad != nullptr ? grad + done * ldg : grad,
+                        ldg, part, status, 1, inv_rows100, done);
+        }
+    } else if (dense_tile && form >= 1) {
+        // three workgroups per CU, looping over the tiles
         nb = (B + TR - 1) / TR;
-        static const int tile_blocks = env_int("RLVI_MSTEP_BLOCKS", 3 * NUM_CU);
+        const int tile_blocks = tune_get("RLVI_MSTEP_BLOCKS", 3 * cus);
         if (nb > tile_blocks) nb = tile_blocks;
         if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
         const size_t lds = tile_bytes + (size_t)TR * 16 + 16;
-        hipLaunchKernelGGL((mstep_tile_kernel<T, V, G, KMAX>), dim3((unsigned)nb),
-                           dim3(MSTEP_THREADS), lds, st, logits, labels, idx, weights, residuals,
-                           N, B, C, kact, inv_scale, grad, part, status, accum, inv_rows100);
+        rc = launch(mstep_tile_kernel<T, V, G, KMAX>, dim3((unsigned)nb), dim3(MSTEP_THREADS), lds, st,
+                    logits, labels, idx, weights, residuals, N, B, C, kact, inv_scale, grad, part,
+                    status, accum, inv_rows100);
     } else {
+        const int max_blocks = tune_get("RLVI_MSTEP_BLOCKS", MSTEP_MAX_BLOCKS);
         const int64_t rows_per_block = (int64_t)MSTEP_WAVES * R;
         nb = (B + rows_per_block - 1) / rows_per_block;
         if (nb > max_blocks) nb = max_blocks;
         if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
         if (nb < 1) nb = 1;
-        hipLaunchKernelGGL((mstep_kernel<T, V, G, KMAX>), dim3((unsigned)nb), dim3(MSTEP_THREADS),
-                           0, st, logits, ld, labels, idx, weights, residuals, N, B, C, kact,
-                           inv_scale, grad, ldg, part, status, accum, inv_rows100);
+        rc = launch(mstep_kernel<T, V, G, KMAX>, dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st,
+                    logits, ld, labels, idx, weights, residuals, N, B, C, kact, inv_scale, grad, ldg,
+                    part, status, accum, inv_rows100, (int64_t)0);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || out == nullptr) return (int)e;
+    if (rc != 0 || out == nullptr) return rc;
     // the finalize pass clears what it read: records are all-zero outside an accumulate sequence
-    hipLaunchKernelGGL(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 1.0, out, 1);
-    return (int)hipGetLastError();
+    return launch(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 1.0, out, 1);
 }
 
 // Picks the lane group: the smallest G whose lanes need at most 8 vectors each (so the short
@@ -576,7 +892,7 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
                        float inv_scale, T *grad, int64_t ldg, float *out, void *ws,
                        hipStream_t st) {
     const int nv = (C + V - 1) / V;
-    static const int force_g = env_int("RLVI_MSTEP_G", 0);
+    const int force_g = tune_get("RLVI_MSTEP_G", 0);
 #define RLVI_CASE(G_, K_)                                                                        \
     return launch_mstep<T, V, G_, K_>(logits, ld, labels, idx, weights, residuals, N, B, C,      \
                                       (nv + G_ - 1) / G_, inv_scale, grad, ldg, out, ws, st)
@@ -607,7 +923,12 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
             if (k <= 4) RLVI_CASE(1, 4);
             RLVI_CASE(1, 8);
         case 2: if (k <= 4) RLVI_CASE(2, 4); RLVI_CASE(2, 8);
-        case 4: if (k <= 4) RLVI_CASE(4, 4); RLVI_CASE(4, 8);
+        case 4:
+            if (k <= 4) RLVI_CASE(4, 4);
+            if (k == 5) RLVI_CASE(4, 5);
+            if (k == 6) RLVI_CASE(4, 6);
+            if (k == 7) RLVI_CASE(4, 7);
+            RLVI_CASE(4, 8);
         case 8: if (k <= 4) RLVI_CASE(8, 4); RLVI_CASE(8, 8);
         case 16: if (k <= 4) RLVI_CASE(16, 4); RLVI_CASE(16, 8);
         case 32: if (k <= 4) RLVI_CASE(32, 4); RLVI_CASE(32, 8);
@@ -678,7 +999,6 @@ extern "C" int rlvi_mstep_fwd_bwd_bf16(const uint16_t *logits, int64_t ld, const
 extern "C" int rlvi_mstep_reduce_f32(float *out, double scale, void *ws, void *stream) {
     if (!out || !ws) return RLVI_E_NULL;
     double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + rlvi::WS_PART_OFF);
-    hipLaunchKernelGGL(rlvi::mstep_finalize_kernel, dim3(1), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), part, rlvi::MSTEP_MAX_BLOCKS, scale, out, 1);
-    return (int)hipGetLastError();
+    return rlvi::launch(rlvi::mstep_finalize_kernel, dim3(1), dim3(256), 0,
+                        static_cast<hipStream_t>(stream), part, (int)rlvi::MSTEP_MAX_BLOCKS, scale, out, 1);
 }

@@ -3,20 +3,65 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 #include "rlvi_hip.h"
 
 namespace rlvi {
 
 constexpr int WAVE = 64;
-constexpr int NUM_CU = 256;
-constexpr int MAX_COOP_WG = 256;        // one workgroup per CU for the cooperative kernels
+constexpr int NUM_CU_DEFAULT = 256;     // MI355X; launchers ask the runtime (device_info())
+constexpr int MAX_COOP_WG = 256;        // exchange slots in the workspace: at most this many exchanging workgroups
+
+// ---- host side (devinfo.hip) -------------------------------------------------------------
+struct DeviceInfo {
+    int cus;          // compute units of the current device
+    int lds_per_cu;   // bytes
+};
+const DeviceInfo &device_info();
+// Integer knob: rlvi_tune_set() value, else the environment variable of that name, else dflt.
+int tune_get(const char *name, int dflt);
+// Workgroups that are provably co-resident given the occupancy API's answer for one CU.
+int coop_blocks_from_occupancy(int per_cu_api, int block_threads, int cus);
+// Number of co-resident workgroups of `kernel` (block threads, dynamic LDS bytes) on this device.
+template <class K>
+inline int coop_blocks(K kernel, int block_threads, size_t dyn_lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_lds) != hipSuccess)
+        per_cu = 0;
+    return coop_blocks_from_occupancy(per_cu, block_threads, device_info().cus);
+}
+// Same, cached per (kernel, device): one occupancy query per kernel instantiation and device.
+int coop_cap_cached(const void *kernel, int block_threads, size_t dyn_lds);
+template <class K>
+inline int coop_cap(K kernel, int block_threads, size_t dyn_lds = 0) {
+    return coop_cap_cached(reinterpret_cast<const void *>(kernel), block_threads, dyn_lds);
+}
+// Launch with the launch's OWN return code (hipLaunchKernel), not the process-wide sticky error:
+// a stale error of somebody else's call is neither reported as ours nor cleared for its owner.
+template <typename... KArgs, size_t... I>
+inline int launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                       std::tuple<KArgs...> &vals, std::index_sequence<I...>) {
+    void *ptrs[] = {static_cast<void *>(&std::get<I>(vals))..., nullptr};
+    return (int)hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, lds, st);
+}
+template <typename... KArgs, typename... Args>
+inline int launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                  Args... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};
+    return launch_impl(kernel, grid, block, lds, st, vals, std::index_sequence_for<KArgs...>{});
+}
 
 // ---------------------------------------------------------------------------------------
 // Workspace layout (bytes).  Control words first, each group on its own 256-B line.
 // ---------------------------------------------------------------------------------------
 struct WsHeader {
     int32_t status;          // sticky RLVI_ST_* flags
-    uint32_t pad0[63];
+    uint32_t pad0a;
+    unsigned long long spin_ticks;   // bound of every inter-workgroup wait, 100 MHz ticks (0: default)
+    uint32_t pad0[60];
     uint32_t mstep_ticket;   // last-block-done counter of the M-step kernel (self-resetting)
     uint32_t pad1[63];
     uint32_t epoch_base;     // tag base of the exchange slots (advanced by every coop kernel)
@@ -37,7 +82,7 @@ constexpr size_t WS_XCHG2_BYTES = 2ull * MAX_COOP_WG * XCHG2_GRANULES * 8;     /
 constexpr size_t WS_TRAJ_OFF = WS_XCHG2_OFF + WS_XCHG2_BYTES;
 constexpr size_t WS_TRAJ_BYTES = 512;
 constexpr size_t WS_PART_OFF = WS_TRAJ_OFF + WS_TRAJ_BYTES;
-constexpr int MSTEP_MAX_BLOCKS = 1024;
+constexpr int MSTEP_MAX_BLOCKS = 1024;   // partial records (and so workgroups) of one M-step launch
 constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
 constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
 // third exchange region (large-N trajectory E-step, estep_trajb.hip), 48-byte records of six
@@ -51,8 +96,18 @@ constexpr size_t WS_XCHG3B_OFF = WS_XCHG3A_OFF + WS_XCHG3A_BYTES;
 #endif
 constexpr int XCHG3B_REPLICAS = RLVI_XCHG3B_REPLICAS;     // the per-node totals are published in 8 copies (one per 32 pollers)
 constexpr size_t WS_XCHG3B_BYTES = 2ull * XCHG3B_REPLICAS * 64 * XCHG3_GRANULES * 8;   // 48 KiB
+// fourth exchange region (radix-descent threshold, threshold.hip): 32-byte records of four self-tagged
+// granules {count, min key, sum lo, sum hi} per (bin, workgroup): stage A [2 parities][256 bins][256
+// workgroups], stage B (the per-bin totals) [2][8 replicas][256 bins]
+constexpr int THR_BINS = 256;
+constexpr int XCHG4_GRANULES = 4;
+constexpr int XCHG4B_REPLICAS = 8;
+constexpr size_t WS_XCHG4A_OFF = WS_XCHG3B_OFF + WS_XCHG3B_BYTES;
+constexpr size_t WS_XCHG4A_BYTES = 2ull * THR_BINS * MAX_COOP_WG * XCHG4_GRANULES * 8;        // 4 MiB
+constexpr size_t WS_XCHG4B_OFF = WS_XCHG4A_OFF + WS_XCHG4A_BYTES;
+constexpr size_t WS_XCHG4B_BYTES = 2ull * XCHG4B_REPLICAS * THR_BINS * XCHG4_GRANULES * 8;    // 128 KiB
 // partial Gram matrices of the weighted-least-squares kernel: 8 workgroups x 64 x 64 doubles
-constexpr size_t WS_WLS_OFF = WS_XCHG3B_OFF + WS_XCHG3B_BYTES;
+constexpr size_t WS_WLS_OFF = WS_XCHG4B_OFF + WS_XCHG4B_BYTES;
 constexpr int WLS_MAX_WG = 8;
 constexpr size_t WS_WLS_BYTES = (size_t)WLS_MAX_WG * 64 * 64 * 8;               // 256 KiB
 constexpr size_t WS_SCRATCH_OFF = WS_WLS_OFF + WS_WLS_BYTES;

@@ -58,7 +58,14 @@ __device__ __forceinline__ double wave_reduce(double v) {
     return group_allreduce<WAVE>(v, OpFn<Op>());
 }
 
-constexpr unsigned long long SPIN_BOUND_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock
+// Default bound of an inter-workgroup wait: 100 ms of the 100 MHz wall clock (an exchange takes
+// ~1 us; the bound only ends a launch whose workgroups cannot all be resident, e.g. beside another
+// process's kernels).  rlvi_workspace_init writes RLVI_SPIN_BOUND_MS into the workspace header.
+constexpr unsigned long long SPIN_BOUND_DEFAULT_TICKS = 10000000ull;
+__device__ __forceinline__ unsigned long long spin_bound(const WsHeader *hdr) {
+    const unsigned long long t = hdr->spin_ticks;
+    return t != 0ull ? t : SPIN_BOUND_DEFAULT_TICKS;
+}
 
 template <int BLOCK>
 struct Coop {
@@ -67,6 +74,7 @@ struct Coop {
     uint32_t tag;       // tag of the NEXT exchange
     int step;           // exchanges done so far
     int nwg;
+    unsigned long long bound;   // spin bound, wall-clock ticks
     bool dead;          // a wait timed out: stop exchanging, results are invalid
 
     static constexpr int NW = BLOCK / WAVE;
@@ -83,6 +91,7 @@ struct Coop {
                                 __HIP_MEMORY_SCOPE_AGENT) + 1u;
         step = 0;
         nwg = nwg_;
+        bound = spin_bound(hdr);
         dead = false;
     }
 
@@ -173,7 +182,7 @@ struct Coop {
                     }
                     if (__all(ok)) break;
                     // the wall clock is read only every 64 polls: keep the poll loop tight
-                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SPIN_BOUND_TICKS) {
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > bound) {
                         timeout = true;
                         break;
                     }

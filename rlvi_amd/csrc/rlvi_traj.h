@@ -1,6 +1,5 @@
-// Shared by the two trajectory E-step kernels (estep_traj.hip: one node per workgroup, medium N;
-// estep_trajb.hip: all nodes per workgroup over a small slice, large N): the warm-start state kept
-// in the workspace and the scalar recurrence one wave runs on the gathered per-node totals.
+// The trajectory E-step (estep_trajb.hip): the warm-start state kept in the workspace and the
+// scalar recurrence one wave runs on the gathered per-node totals.
 #pragma once
 #include "rlvi_coop.h"
 

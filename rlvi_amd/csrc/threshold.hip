@@ -190,268 +190,324 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// Fast form for weights in [0, 1] (what the E-step produces): (1 - pi) * 2^24 is an exact
-// integer <= 2^24, so the prefix sums are plain integer sums (u32 per thread, u64 across the
-// workgroup) -- six 32-bit VALU operations per key and bisection round instead of fp64 adds.
-// The first pass checks the range; outside [0, 1] the generic kernel above is used instead
-// (signalled through *fallback).
+// Radix descent for weights in [0, 1] (what the E-step produces): the product path.
+//
+// (1 - pi) * 2^24 is an exact integer <= 2^24, so every prefix sum is a plain integer sum and the
+// reference's predicate fl32(prefix) <= beta is evaluated on exactly its numbers.  For pi >= 0 the
+// fp32 bit pattern is an order-preserving key.  c* -- the smallest key c such that the keys >= c
+// fit together -- is found 8 bits per pass, most significant first: every workgroup builds a
+// 256-bin histogram {count, sum of (1-pi) units, smallest key} of its keys inside the current
+// prefix, ONE two-stage record exchange (the protocol of estep_trajb.hip: workgroup w publishes a
+// record per bin, workgroup b adds bin b's records in a fixed order and publishes the total in 8
+// replicas, everybody reads the 256 totals) gives every workgroup identical totals, a suffix scan
+// finds the first bin whose suffix fits, and the descent continues in the bin below it.  Four
+// exchanges instead of the ~20 dependent ones of a bisection (71 us at N = 65 536), the same exact
+// arithmetic, the same bits.  After the last pass the bin below IS the reference's "next key
+// below" (v, with its multiplicity), and the smallest key above comes from the min field.
+// Outside [0, 1] (NaN, -0.0, negative, > 1): *fallback = 1 and the generic fp64 kernel above runs
+// in the same stream.  G <= 256 workgroups of 256 threads, all provably co-resident (launcher);
+// G == 1 needs no exchange at all.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, int tag) {
-    __shared__ unsigned long long sh[2][THR_NW];
-    __shared__ unsigned long long out[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_sum(v);
-    if (lane == 0) sh[tag & 1][wave] = v;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long t = lane < THR_NW ? sh[tag & 1][lane] : 0ull;
-        t = wave_sum(t);
-        if (lane == 0) out[tag & 1] = t;
-    }
-    __syncthreads();
-    return out[tag & 1];      // double-buffered by `tag`: the next call may start before all read
-}
+constexpr int THQ_BLOCK = 256;
+constexpr int THQ_NW = THQ_BLOCK / WAVE;
+typedef unsigned int thq_vu4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t one_minus_u(float p) {
     return (uint32_t)__float2uint_rn((1.0f - p) * 16777216.0f);
 }
 
+struct ThqHist {                       // one histogram: what a workgroup publishes / what comes back
+    unsigned long long sum[THR_BINS];
+    uint32_t cnt[THR_BINS];
+    uint32_t mn[THR_BINS];
+};
+
+struct ThqShared {
+    ThqHist h;                         // local histogram, then the totals
+    unsigned long long wsum[THQ_NW];   // cross-wave scratch of the scans / reductions
+    unsigned long long wcnt[THQ_NW];
+    uint32_t wmin[THQ_NW];
+    uint32_t wtrue[THQ_NW];
+    unsigned long long r_sum, r_cnt;   // results of a pass
+    uint32_t r_min, r_b1;
+    int dead;
+};
+
+// 32-byte record = four granules {tag32 | payload32}: {count, min key, sum lo, sum hi}
+__device__ __forceinline__ void thq_store(gu64 *p, uint32_t tag, uint32_t cnt, uint32_t mn,
+                                          unsigned long long sum) {
+    // two 16-byte write-through stores; every 8-byte granule carries its own tag, so tearing
+    // between granules is harmless
+    const thq_vu4 q0 = {cnt, tag, mn, tag};
+    const thq_vu4 q1 = {(uint32_t)sum, tag, (uint32_t)(sum >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                 "s_nop 1"
+                 :
+                 : "v"((unsigned long long)(uintptr_t)p), "v"(q0), "v"(q1)
+                 : "memory");
+}
+__device__ __forceinline__ bool thq_load(gu64 *p, uint32_t tag, uint32_t &cnt, uint32_t &mn,
+                                         unsigned long long &sum) {
+    thq_vu4 q0, q1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1)
+                 : "v"((unsigned long long)(uintptr_t)p)
+                 : "memory");
+    cnt = q0.x; mn = q0.z;
+    sum = ((unsigned long long)q1.z << 32) | q1.x;
+    return q0.y == tag && q0.w == tag && q1.y == tag && q1.w == tag;
+}
+
+// Totals of the per-workgroup histograms sh.h over the G workgroups, back into sh.h (identical
+// on every workgroup).  All threads call; returns false after a timeout (sh.dead set).
+__device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bufB, uint32_t tag,
+                                             int xstep, int G, WsHeader *hdr,
+                                             unsigned long long spin_ticks) {
+    if (G == 1) return true;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int b = (int)blockIdx.x;
+    gu64 *A = bufA + (size_t)(xstep & 1) * THR_BINS * MAX_COOP_WG * XCHG4_GRANULES;
+    gu64 *B = bufB + (size_t)(xstep & 1) * XCHG4B_REPLICAS * THR_BINS * XCHG4_GRANULES;
+    // ---- stage A: thread t publishes this workgroup's record of bin t
+    thq_store(A + ((size_t)tid * MAX_COOP_WG + b) * XCHG4_GRANULES, tag, sh.h.cnt[tid], sh.h.mn[tid],
+              sh.h.sum[tid]);
+    // ---- stage B: workgroup b adds the records of bins b, b + G, ... (thread w = workgroup w)
+    for (int bin = b; bin < THR_BINS; bin += G) {
+        uint32_t c = 0, mn = 0xFFFFFFFFu;
+        unsigned long long sm = 0ull;
+        bool timeout = false;
+        if (tid < G) {
+            gu64 *p = A + ((size_t)bin * MAX_COOP_WG + tid) * XCHG4_GRANULES;
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spin = 0;; ++spin) {
+                if (thq_load(p, tag, c, mn, sm)) break;
+                if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+            }
+        }
+        if (timeout) { c = 0; mn = 0xFFFFFFFFu; sm = 0ull; sh.dead = 1; }
+        unsigned long long tc = wave_sum((unsigned long long)c);
+        unsigned long long ts = wave_sum(sm);
+        uint32_t tm = (uint32_t)wave_min((unsigned long long)mn);
+        if (lane == 0) { sh.wcnt[wave] = tc; sh.wsum[wave] = ts; sh.wmin[wave] = tm; }
+        __syncthreads();
+        if (wave == 0) {
+            tc = 0ull; ts = 0ull; tm = 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < THQ_NW; ++w) {      // fixed order (integers: any order gives these bits)
+                tc += sh.wcnt[w]; ts += sh.wsum[w]; tm = sh.wmin[w] < tm ? sh.wmin[w] : tm;
+            }
+            // lane l stores granule l & 3 of replica l >> 2: one 8-byte store per lane
+            if (lane < XCHG4_GRANULES * XCHG4B_REPLICAS && sh.dead == 0) {
+                const int gq = lane & 3, rep = lane >> 2;
+                const uint32_t v = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
+                                                                           : (uint32_t)(ts >> 32);
+                __hip_atomic_store(B + ((size_t)rep * THR_BINS + bin) * XCHG4_GRANULES + gq,
+                                   ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();                             // wcnt / wsum / wmin are rewritten by the next bin
+    }
+    // ---- everybody: the 256 totals (thread t = bin t), replica blockIdx % 8
+    {
+        uint32_t c = 0, mn = 0xFFFFFFFFu;
+        unsigned long long sm = 0ull;
+        bool timeout = false;
+        if (sh.dead == 0) {
+            gu64 *p = B + ((size_t)(b & (XCHG4B_REPLICAS - 1)) * THR_BINS + tid) * XCHG4_GRANULES;
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spin = 0;; ++spin) {
+                if (thq_load(p, tag, c, mn, sm)) break;
+                if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+            }
+        }
+        if (timeout) sh.dead = 1;
+        sh.h.cnt[tid] = c; sh.h.mn[tid] = mn; sh.h.sum[tid] = sm;
+    }
+    __syncthreads();
+    if (sh.dead != 0) {
+        if (tid == 0) atomicOr(&hdr->status, RLVI_ST_TIMEOUT);
+        return false;
+    }
+    return true;
+}
+
 template <int E, bool TRUNC>
-__global__ __launch_bounds__(THR_BLOCK) void threshold_fast_kernel(float *__restrict__ w, int64_t N,
-                                                                   float alpha,
-                                                                   float *__restrict__ thr_io,
-                                                                   uint8_t *__restrict__ mask,
-                                                                   int64_t *__restrict__ kept_out,
-                                                                   int32_t *__restrict__ fallback) {
-    float p[E];
-    int cnt = 0;
-    unsigned long long tot = 0ull;
-    float pmin = __builtin_inff(), pmax = -__builtin_inff();
+__global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
+    float *__restrict__ w, int64_t N, float alpha, float *__restrict__ thr_io,
+    uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out, int32_t *__restrict__ fallback,
+    void *ws) {
+    __shared__ ThqShared sh;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    char *wsb = static_cast<char *>(ws);
+    WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
+    gu64 *bufA = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG4A_OFF));
+    gu64 *bufB = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG4B_OFF));
+    uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned long long spin_ticks = spin_bound(hdr);
+    int xstep = 0;
+    if (tid == 0) sh.dead = 0;
+    // (read before the first exchange: workgroup 0 overwrites it after the last one)
+    const float prev = TRUNC ? *thr_io : 0.0f;
+
+    const int64_t L = (N + G - 1) / G;
+    const int64_t lo_i = (int64_t)b * L < N ? (int64_t)b * L : N;
+    const int64_t hi_i = lo_i + L < N ? lo_i + L : N;
+    uint32_t k[E];
+    bool have[E];
+    uint32_t nbad = 0;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const int64_t i = (int64_t)j * THR_BLOCK + threadIdx.x;
-        if (i < N) {
-            p[j] = w[i];
-            cnt = j + 1;
-            pmin = fminf(pmin, p[j]);
-            pmax = fmaxf(pmax, p[j]);
-            tot += one_minus_u(p[j]);
-        } else {
-            p[j] = -1.0f;          // never >= a candidate in [0, 1]
-        }
+        const int64_t i = lo_i + tid + (int64_t)j * THQ_BLOCK;
+        have[j] = i < hi_i;
+        k[j] = have[j] ? __float_as_uint(w[i]) : 0u;
+        if (have[j] && k[j] > 0x3F800000u) { ++nbad; have[j] = false; }   // NaN, negative, -0.0, > 1
     }
-    Red3 r = block_reduce3((double)0.0, (unsigned long long)f32_key(pmin), (unsigned long long)f32_key(pmax));
-    const float gmin = key_f32((uint32_t)r.a), gmax = key_f32((uint32_t)r.b);
-    if (!(gmin >= 0.0f && gmax <= 1.0f) || (__float_as_uint(gmin) >> 31)) {   // NaN, -0.0 too
-        if (threadIdx.x == 0) *fallback = 1;
-        return;
-    }
-    int tag = 0;
-    const unsigned long long total = block_sum_u64(tot, tag++);
-    const float beta = (float)((double)total * (1.0 / 16777216.0)) * alpha;     // (:43-44)
-    auto pred = [&](unsigned long long s_int) {       // fl32(prefix) <= beta   (:46-47)
+
+    unsigned long long S_base = 0ull, cnt_base = 0ull;   // sum / count of the keys above the current range
+    uint32_t above = 0xFFFFFFFFu;                        // smallest key above the current range
+    uint32_t prefix = 0u;                                // the high bits fixed so far
+    uint32_t gmin = 0u, below_cnt = 0u;
+    float beta = 0.0f;
+    bool all_inside = false, ok = true;
+    auto pred = [&](unsigned long long s_int) {          // fl32(prefix sum) <= beta   (:46-47)
         return (float)((double)s_int * (1.0 / 16777216.0)) <= beta;
     };
 
-    // smallest candidate value c (as an fp32 bit pattern; weights >= 0 so bits are ordered) in
-    // [gmin, next(gmax)] with  sum_{pi >= c} (1 - pi)  <= beta
-    unsigned long long lo = __float_as_uint(gmin), hi = (unsigned long long)__float_as_uint(gmax) + 1ull;
-    while (lo < hi) {
-        const unsigned long long mid = lo + ((hi - lo) >> 1);
-        const float c = __uint_as_float((uint32_t)mid);
-        uint32_t s = 0;
+#pragma unroll 1
+    for (int level = 0; level < 4 && ok && !all_inside; ++level) {
+        const int shift = 24 - 8 * level;
+        // ---- local histogram of the keys inside the current prefix
+        sh.h.cnt[tid] = 0u; sh.h.mn[tid] = 0xFFFFFFFFu; sh.h.sum[tid] = 0ull;
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < E; ++j) s += (p[j] >= c) ? one_minus_u(p[j]) : 0u;
-        if (pred(block_sum_u64((unsigned long long)s, tag++))) hi = mid; else lo = mid + 1ull;
-    }
-    // c* = lo.  lo == bits(gmax)+1 means even the top group alone does not fit.
-    const bool top_empty = lo > (unsigned long long)__float_as_uint(gmax);
-    const float cstar = top_empty ? __builtin_inff() : __uint_as_float((uint32_t)lo);
-    uint32_t s_in = 0, n_in = 0;
-    float below = -1.0f, above = __builtin_inff();       // max{pi < c*}, min{pi >= c*}
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        if (j < cnt) {
-            if (p[j] >= cstar) { s_in += one_minus_u(p[j]); ++n_in; above = fminf(above, p[j]); }
-            else below = fmaxf(below, p[j]);
+        for (int j = 0; j < E; ++j) {
+            const bool in = have[j] && (level == 0 || (k[j] >> (shift + 8)) == prefix);
+            if (in) {
+                const int bin = (int)((k[j] >> shift) & 0xFFu);
+                atomicAdd(&sh.h.cnt[bin], 1u);
+                atomicAdd(&sh.h.sum[bin], (unsigned long long)one_minus_u(__uint_as_float(k[j])));
+                atomicMin(&sh.h.mn[bin], k[j]);
+            }
         }
+        if (level == 0 && nbad != 0u) atomicAdd(&sh.h.cnt[THR_BINS - 1], nbad);   // no valid key has top byte 0xFF
+        __syncthreads();
+        ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks);
+        ++tag; ++xstep;
+        if (!ok) break;
+        if (level == 0 && sh.h.cnt[THR_BINS - 1] != 0u) {   // out of [0, 1]: the generic kernel takes over
+            if (b == 0 && tid == 0) *fallback = 1;
+            ok = false;
+            break;
+        }
+        // ---- suffix scan over the bins: thread t holds T(t) = S_base + sum of bins >= t
+        unsigned long long sfx = sh.h.sum[tid], cfx = (unsigned long long)sh.h.cnt[tid];
+        uint32_t mfx = sh.h.mn[tid];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const unsigned long long os = __shfl_down(sfx, d, WAVE), oc = __shfl_down(cfx, d, WAVE);
+            const uint32_t om = __shfl_down(mfx, d, WAVE);
+            if (lane + d < WAVE) { sfx += os; cfx += oc; mfx = om < mfx ? om : mfx; }
+        }
+        if (lane == 0) { sh.wsum[wave] = sfx; sh.wcnt[wave] = cfx; sh.wmin[wave] = mfx; }
+        __syncthreads();
+#pragma unroll
+        for (int wv = 1; wv < THQ_NW; ++wv)
+            if (wave + wv < THQ_NW) {
+                sfx += sh.wsum[wave + wv]; cfx += sh.wcnt[wave + wv];
+                mfx = sh.wmin[wave + wv] < mfx ? sh.wmin[wave + wv] : mfx;
+            }
+        if (level == 0) {
+            // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44): the total is T(0)
+            if (tid == 0) { sh.r_sum = sfx; sh.r_min = mfx; }
+            __syncthreads();
+            beta = (float)((double)sh.r_sum * (1.0 / 16777216.0)) * alpha;
+            gmin = sh.r_min;
+            __syncthreads();
+        }
+        // the predicate is monotone along the bins (T is non-increasing): b1 = number of bins that fail
+        const bool fits = pred(S_base + sfx);
+        const unsigned long long bal = __ballot(fits);
+        if (lane == 0) sh.wtrue[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t ntrue = 0;
+#pragma unroll
+        for (int wv = 0; wv < THQ_NW; ++wv) ntrue += sh.wtrue[wv];
+        const int b1 = THR_BINS - (int)ntrue;             // first bin whose suffix fits (256: none)
+        if (b1 == 0) {
+            // every key of the range fits (only possible at level 0: a deeper range was entered
+            // because it does NOT fit as a whole): count = N, threshold = smallest weight
+            all_inside = true;
+            break;
+        }
+        if (tid == b1 || (b1 == THR_BINS && tid == 0)) {
+            sh.r_sum = b1 == THR_BINS ? 0ull : sfx;
+            sh.r_cnt = b1 == THR_BINS ? 0ull : cfx;
+            sh.r_min = b1 == THR_BINS ? 0xFFFFFFFFu : mfx;
+        }
+        __syncthreads();
+        S_base += sh.r_sum;
+        cnt_base += sh.r_cnt;
+        above = sh.r_min < above ? sh.r_min : above;
+        prefix = (prefix << 8) | (uint32_t)(b1 - 1);
+        below_cnt = sh.h.cnt[b1 - 1];
+        __syncthreads();                                  // r_* and the histogram are rewritten by the next pass
     }
-    const unsigned long long S = block_sum_u64((unsigned long long)s_in, tag++);
-    const unsigned long long cnt_in = block_sum_u64((unsigned long long)n_in, tag++);
-    r = block_reduce3(0.0, (unsigned long long)f32_key(above), (unsigned long long)f32_key(below));
-    above = key_f32((uint32_t)r.a);
-    below = key_f32((uint32_t)r.b);
 
-    float thr;
-    if (below < 0.0f) {
-        thr = gmin;                                   // every element inside: count = N
-    } else {
-        uint32_t m = 0;
-#pragma unroll
-        for (int j = 0; j < E; ++j) m += (j < cnt && p[j] == below) ? 1u : 0u;
-        const unsigned long long mult = block_sum_u64((unsigned long long)m, tag++);
-        const unsigned long long t = one_minus_u(below);
-        long long jl = 0, jh = (long long)mult;       // pred(jl) true, pred(jh) false
-        while (jh - jl > 1) {
-            const long long jm = jl + ((jh - jl) >> 1);
-            if (pred(S + (unsigned long long)jm * t)) jl = jm; else jh = jm;
+    float thr = 0.0f;
+    if (ok) {
+        if (all_inside) {
+            thr = __uint_as_float(gmin);
+        } else {
+            // prefix is now the full key v = the largest key whose inclusion (all copies) does not
+            // fit; S_base / cnt_base are the sum / count of the keys above it
+            const uint32_t v = prefix;
+            const unsigned long long t = one_minus_u(__uint_as_float(v));
+            long long jl = 0, jh = (long long)below_cnt;  // pred(S + jl t) true, pred(S + jh t) false
+            while (jh - jl > 1) {
+                const long long jm = jl + ((jh - jl) >> 1);
+                if (pred(S_base + (unsigned long long)jm * t)) jl = jm; else jh = jm;
+            }
+            const long long j = jl;
+            if (cnt_base + (unsigned long long)j == 0ull) thr = __uint_as_float(gmin);   // last_index = -1 wraps (:47-48)
+            else if (j >= 1) thr = __uint_as_float(v);
+            else thr = __uint_as_float(above);
         }
-        const long long j = pred(S) ? jl : 0;         // S = 0 (empty top) always fits: beta >= 0
-        if (cnt_in + (unsigned long long)j == 0ull) thr = gmin;     // last_index = -1 wraps (:47-48)
-        else if (j >= 1) thr = below;
-        else thr = above;
+        if (TRUNC && !(thr > prev)) thr = prev;           // threshold = max(threshold, criterion) (:102)
     }
-    if (TRUNC) {
-        const float prev = *thr_io;
-        if (!(thr > prev)) thr = prev;                // threshold = max(threshold, criterion) (:102)
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *thr_io = thr;
-    if (TRUNC) {
+
+    if (TRUNC && ok) {
         uint32_t kept = 0;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const int64_t i = (int64_t)j * THR_BLOCK + threadIdx.x;
-            if (j < cnt) {
-                float x = p[j];
-                if (x < thr) { x = 0.0f; w[i] = 0.0f; }      // :103
-                const bool mk = x > thr;                     // main.py:343
+            const int64_t i = lo_i + tid + (int64_t)j * THQ_BLOCK;
+            if (have[j]) {
+                float x = __uint_as_float(k[j]);
+                if (x < thr) { x = 0.0f; w[i] = 0.0f; }       // :103
+                const bool mk = x > thr;                      // main.py:343
                 if (mask != nullptr) mask[i] = mk ? 1 : 0;
                 kept += mk ? 1u : 0u;
             }
         }
-        const unsigned long long k = block_sum_u64((unsigned long long)kept, tag++);
-        if (threadIdx.x == 0 && kept_out != nullptr) *kept_out = (int64_t)k;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------
-// Cooperative form for populations beyond one workgroup's registers (N > 65 536: Food-101's
-// 75 750, web-scale label-noise sets of ~1e6): 240 workgroups of 256 threads hold N/240 keys each
-// in registers and run the SAME search with every block-wide reduction followed by one record
-// exchange (rlvi_coop.h: sums / min / max formed in a fixed order, identical on every workgroup;
-// the fp64 sums of multiples of 2^-24 are exact, so the order does not matter anyway).  An
-// exchange carries two values, so the search is ternary: two candidate keys per step, 19-20 steps
-// for the 2^30 candidate patterns instead of 30.  ~25 exchanges of ~2.6 us whatever N is, against
-// 0.39 ms (N = 75 750) ... 4.8 ms (N = 1e6) for one workgroup re-reading the keys from L2.
-// ---------------------------------------------------------------------------------------
-constexpr int THC_BLOCK = 256;
-constexpr int THC_G = 240;
-
-template <int E, bool TRUNC>
-__global__ __launch_bounds__(THC_BLOCK) void threshold_coop_kernel(float *__restrict__ w, int64_t N,
-                                                                   float alpha,
-                                                                   float *__restrict__ thr_io,
-                                                                   uint8_t *__restrict__ mask,
-                                                                   int64_t *__restrict__ kept_out,
-                                                                   void *ws) {
-    Coop<THC_BLOCK> coop;
-    coop.init(ws, (int)gridDim.x);
-    // (read before the first exchange: workgroup 0 overwrites it after the last one)
-    const float prev = TRUNC ? *thr_io : 0.0f;
-    const int64_t L = (N + gridDim.x - 1) / gridDim.x;
-    const int64_t lo_i = (int64_t)blockIdx.x * L;
-    const int64_t hi_i = lo_i + L < N ? lo_i + L : N;
-    uint32_t k[E];
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int64_t i = lo_i + threadIdx.x + (int64_t)j * THC_BLOCK;
-        if (i < hi_i) { k[j] = f32_key(w[i]); cnt = j + 1; } else k[j] = 0;
-    }
-    auto for_each = [&](auto fn) {
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (j < cnt) fn(k[j], lo_i + threadIdx.x + (int64_t)j * THC_BLOCK);
-    };
-
-    // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44); global min / max key
-    double tot = 0.0, dmin = __builtin_inf(), dmax = -__builtin_inf(), zero = 0.0;
-    for_each([&](uint32_t key, int64_t) {
-        tot += one_minus(key);
-        dmin = (double)key < dmin ? (double)key : dmin;
-        dmax = (double)key > dmax ? (double)key : dmax;
-    });
-    coop.template allreduce2<OpSum, OpMin>(tot, dmin);
-    coop.template allreduce2<OpMax, OpSum>(dmax, zero);
-    const float beta = (float)tot * alpha;
-    const unsigned long long kmin = (unsigned long long)dmin, kmax = (unsigned long long)dmax;
-
-    // smallest c in [kmin, kmax+1] with fl32(S(c)) <= beta; invariant: the predicate holds at hi
-    unsigned long long lo = kmin, hi = kmax + 1ull;
-    const bool any_ok = 0.0f <= beta;           // S(kmax+1) = 0
-    while (any_ok && lo < hi && !coop.dead) {
-        const unsigned long long span = hi - lo;
-        const unsigned long long m1 = span >= 3 ? lo + span / 3 : lo + (span >> 1);
-        const unsigned long long m2 = span >= 3 ? lo + 2 * (span / 3) + 1 : hi;     // m1 < m2 <= hi
-        double s1 = 0.0, s2 = 0.0;
-        for_each([&](uint32_t key, int64_t) {
-            const double t = one_minus(key);
-            s1 += (key >= m1) ? t : 0.0;
-            s2 += (key >= m2) ? t : 0.0;
-        });
-        coop.template allreduce2<OpSum, OpSum>(s1, s2);
-        if ((float)s1 <= beta) hi = m1;
-        else if (m2 >= hi || (float)s2 <= beta) { lo = m1 + 1ull; hi = m2 < hi ? m2 : hi; }
-        else lo = m2 + 1ull;
-    }
-    const unsigned long long cstar = lo;
-
-    double s_in = 0.0, n_in = 0.0, above = __builtin_inf(), below = -1.0;   // min{k >= c*}, max{k < c*}
-    for_each([&](uint32_t key, int64_t) {
-        if (any_ok && key >= cstar) {
-            s_in += one_minus(key);
-            n_in += 1.0;
-            above = (double)key < above ? (double)key : above;
-        } else {
-            below = (double)key > below ? (double)key : below;
+        if (kept_out != nullptr) {                            // uniform: one more exchange, bin 0 carries the count
+            sh.h.cnt[tid] = 0u; sh.h.mn[tid] = 0xFFFFFFFFu; sh.h.sum[tid] = 0ull;
+            __syncthreads();
+            const unsigned long long kw = wave_sum((unsigned long long)kept);
+            if (lane == 0) atomicAdd(&sh.h.sum[0], kw);
+            __syncthreads();
+            ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks);
+            ++tag; ++xstep;
+            if (ok && b == 0 && tid == 0) *kept_out = (int64_t)sh.h.sum[0];
         }
-    });
-    coop.template allreduce2<OpSum, OpSum>(s_in, n_in);
-    coop.template allreduce2<OpMin, OpMax>(above, below);
-    const double S = s_in, cnt_in = n_in;
-
-    float thr;
-    if (below < 0.0) {
-        thr = key_f32((uint32_t)kmin);           // every element is inside: count = N
-    } else {
-        const uint32_t v = (uint32_t)below;
-        double mult = 0.0;
-        zero = 0.0;
-        for_each([&](uint32_t key, int64_t) { mult += (key == v) ? 1.0 : 0.0; });
-        coop.template allreduce2<OpSum, OpSum>(mult, zero);
-        // j = #{i in 1..mult : fl32(S + i*t) <= beta}; monotone in i -> binary search
-        const double t = one_minus(v);
-        long long jl = 0, jh = (long long)mult;   // P(jl) true, P(jh) false (minimality of c*)
-        if (!any_ok) jh = 0;
-        while (jh - jl > 1) {
-            const long long jm = jl + ((jh - jl) >> 1);
-            if ((float)(S + (double)jm * t) <= beta) jl = jm; else jh = jm;
-        }
-        const long long j = any_ok ? jl : 0;
-        if (cnt_in + (double)j == 0.0) thr = key_f32((uint32_t)kmin);   // last_index = -1 wraps
-        else if (j >= 1) thr = key_f32(v);
-        else thr = key_f32((uint32_t)above);
     }
-    if (TRUNC && !(thr > prev)) thr = prev;       // threshold = max(threshold, criterion)  (:102)
-
-    double kept = 0.0;
-    if (TRUNC) {
-        for_each([&](uint32_t key, int64_t i) {
-            float x = key_f32(key);
-            if (x < thr) { x = 0.0f; w[i] = 0.0f; }          // :103
-            const bool m = x > thr;                          // main.py:343
-            if (mask != nullptr) mask[i] = m ? 1 : 0;
-            kept += m ? 1.0 : 0.0;
-        });
-        zero = 0.0;
-        coop.template allreduce2<OpSum, OpSum>(kept, zero);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *thr_io = thr;
-        if (TRUNC && kept_out != nullptr) *kept_out = (int64_t)kept;
-        coop.finish(ws);
+    if (b == 0 && tid == 0) {
+        if (ok) *thr_io = thr;
+        __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -466,38 +522,50 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
     }
 }
 
-// N <= 16 384: one workgroup, the integer fast form with the weights in registers (16 per thread,
-// 40 us); it hands over to the generic fp64 form (any range) by setting a flag the generic kernel
-// reads at its start -- both are enqueued, the second is a no-op when the first one succeeded.
-// 16 384 < N <= 1 966 080: the cooperative form (85-120 us; one workgroup with 64 keys per thread
-// took 114-134 us up to 65 536 and 0.4-4.8 ms streaming beyond).  Larger: one workgroup, streaming.
+// Every N up to 2 097 152: the radix descent on G = min(256, N / 256, what is provably co-resident)
+// workgroups, handing over to the generic fp64 form (any range) by setting a flag the generic kernel
+// reads at its start -- both are enqueued, the second is a no-op when the first one did the work.
+// Larger: one workgroup, streaming.
 __global__ void threshold_flag_clear(int32_t *flag) { *flag = 0; }
 
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
                             int64_t *kept, void *ws, hipStream_t st) {
     int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
-    static const int64_t coop_nmin = getenv("RLVI_THR_COOP_NMIN") ? atoll(getenv("RLVI_THR_COOP_NMIN")) : (int64_t)THR_BLOCK * 16 + 1;
-    if (N <= (int64_t)THR_BLOCK * 16 && N < coop_nmin) {
-        hipLaunchKernelGGL(threshold_flag_clear, dim3(1), dim3(1), 0, st, flag);
-        hipLaunchKernelGGL((threshold_fast_kernel<16, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N,
-                           alpha, thr, mask, kept, flag);
-        hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha,
-                           thr, mask, kept, flag);
-    } else if (N <= (int64_t)THC_G * THC_BLOCK * 32) {
-        const int64_t L = (N + THC_G - 1) / THC_G;
-#define RLVI_THC(E_)                                                                             \
-    hipLaunchKernelGGL((threshold_coop_kernel<E_, TRUNC>), dim3(THC_G), dim3(THC_BLOCK), 0, st, w, \
-                       N, alpha, thr, mask, kept, ws)
-        if (L <= THC_BLOCK * 2) RLVI_THC(2);
-        else if (L <= THC_BLOCK * 8) RLVI_THC(8);
-        else RLVI_THC(32);
-#undef RLVI_THC
-    } else {
-        hipLaunchKernelGGL((threshold_kernel<0, TRUNC>), dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha,
-                           thr, mask, kept, (const int32_t *)nullptr);
+    int rc = RLVI_E_LIMIT;
+    bool launched = false;
+#define RLVI_THQ(E_)                                                                             \
+    do {                                                                                         \
+        auto kern = threshold_radix_kernel<E_, TRUNC>;                                           \
+        int G = coop_cap(kern, THQ_BLOCK);                                                       \
+        if (G > MAX_COOP_WG) G = MAX_COOP_WG;                                                    \
+        const int64_t want = (N + THQ_BLOCK - 1) / THQ_BLOCK;     /* one key per thread is enough */ \
+        if (G > want) G = (int)want;                                                             \
+        if (G >= 1 && (N + G - 1) / G <= (int64_t)(E_) * THQ_BLOCK) {                            \
+            rc = launch(threshold_flag_clear, dim3(1), dim3(1), 0, st, flag);                    \
+            if (rc == 0)                                                                         \
+                rc = launch(kern, dim3((unsigned)G), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask, \
+                            kept, flag, ws);                                                     \
+            if (rc == 0)                                                                         \
+                rc = launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, \
+                            thr, mask, kept, (const int32_t *)flag);                             \
+            launched = true;                                                                     \
+        }                                                                                        \
+    } while (0)
+    const int64_t Lfull = (N + MAX_COOP_WG - 1) / MAX_COOP_WG;    // slice at the full width
+    if (tune_get("RLVI_THR_RADIX", 1)) {
+        if (Lfull <= THQ_BLOCK * 1) RLVI_THQ(1);
+        else if (Lfull <= THQ_BLOCK * 2) RLVI_THQ(2);
+        else if (Lfull <= THQ_BLOCK * 4) RLVI_THQ(4);
+        else if (Lfull <= THQ_BLOCK * 8) RLVI_THQ(8);
+        else if (Lfull <= THQ_BLOCK * 16) RLVI_THQ(16);
+        else if (Lfull <= THQ_BLOCK * 32) RLVI_THQ(32);
+        if (!launched && N <= (int64_t)THQ_BLOCK * 32) RLVI_THQ(32);   // few co-resident workgroups: longer slices
     }
-    return (int)hipGetLastError();
+#undef RLVI_THQ
+    if (launched) return rc;
+    return launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, thr, mask,
+                  kept, (const int32_t *)nullptr);
 }
 
 }  // namespace rlvi
@@ -532,7 +600,6 @@ extern "C" int rlvi_truncate_f32(float *weights, int64_t N, const float *thr, ui
     if (N <= 0) return RLVI_E_SHAPE;
     int64_t nb = (N + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(truncate_kernel, dim3((unsigned)nb), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), weights, N, thr, mask_gt);
-    return (int)hipGetLastError();
+    return launch(truncate_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream),
+                  weights, N, thr, mask_gt);
 }

@@ -21,10 +21,64 @@ import torch.distributed as dist
 
 
 _INPLACE_GATHER = True
+_RAGGED = False
 
 
 def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if is_dist() else 1
+
+
+def set_ragged(flag=True):
+    """Per-rank batches of one step may differ in length (a hand-rolled sharded loader; torch's
+    DistributedSampler pads to equal lengths and does not need this).  train_rlvi then sums the
+    batch size over the ranks every step (one small all-reduce + host sync per batch) instead of
+    checking once per epoch that the shards were equal."""
+    global _RAGGED
+    _RAGGED = bool(flag)
+
+
+def ragged():
+    return _RAGGED
+
+
+def _host_staged(t, group=None):
+    """gloo has no device-side all-gather: collectives on CUDA tensors are staged through the host."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def check_equal_shards(sizes, group=None):
+    """Once per epoch: every rank ran the same number of batches of the same lengths (what
+    inv_scale = 1/B_local under DDP's gradient averaging assumes).  One small all-gather."""
+    if not is_dist():
+        return
+    from ._lib import RlviError
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    n = torch.tensor([len(sizes)], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(x.item()) for x in ns]
+    if len(set(ns)) != 1:
+        raise RlviError(f"train_rlvi: ranks ran different numbers of batches this epoch ({ns}); "
+                        "shard the loader evenly (torch DistributedSampler does)")
+    mine = torch.tensor(list(sizes), dtype=torch.int64, device=dev)
+    alls = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(alls, mine, group=group)
+    if any(not torch.equal(a, alls[0]) for a in alls):
+        raise RlviError("train_rlvi: per-rank batch lengths differ within a step; either shard evenly "
+                        "(torch DistributedSampler pads) or call rlvi_amd.dist.set_ragged(True)")
+
+
+def mean_scalars(t, group=None):
+    """Mean over the ranks of a small tensor of per-rank means (train_acc, mean batch loss)."""
+    if is_dist():
+        dist.all_reduce(t, group=group)
+        t /= dist.get_world_size(group)
+    return t
 
 
 def shard_range(n, rank, world):
@@ -81,7 +135,10 @@ def exchange_residuals(residuals, idx_local, group=None):
         return
     world = dist.get_world_size(group)
     dev = residuals.device
-    n_local = torch.tensor([idx_local.numel()], dtype=torch.int64, device=dev)
+    staged = _host_staged(residuals, group)
+    cdev = torch.device("cpu") if staged else dev
+    idx_local = idx_local.to(dev)
+    n_local = torch.tensor([idx_local.numel()], dtype=torch.int64, device=cdev)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
     sizes = [int(s.item()) for s in sizes]
@@ -90,10 +147,11 @@ def exchange_residuals(residuals, idx_local, group=None):
     pad_val = torch.zeros(m, dtype=residuals.dtype, device=dev)
     pad_idx[:idx_local.numel()] = idx_local
     pad_val[:idx_local.numel()] = residuals[idx_local]
-    all_idx = torch.empty(world * m, dtype=torch.int64, device=dev)
-    all_val = torch.empty(world * m, dtype=residuals.dtype, device=dev)
-    dist.all_gather_into_tensor(all_idx, pad_idx, group=group)
-    dist.all_gather_into_tensor(all_val, pad_val, group=group)
+    all_idx = torch.empty(world * m, dtype=torch.int64, device=cdev)
+    all_val = torch.empty(world * m, dtype=residuals.dtype, device=cdev)
+    dist.all_gather_into_tensor(all_idx, pad_idx.to(cdev), group=group)
+    dist.all_gather_into_tensor(all_val, pad_val.to(cdev), group=group)
+    all_idx, all_val = all_idx.to(dev), all_val.to(dev)
     for r, s in enumerate(sizes):
         residuals[all_idx[r * m:r * m + s]] = all_val[r * m:r * m + s]
 

@@ -14,6 +14,7 @@ unchanged when `methods` resolves to this package.
 """
 import torch
 
+from .. import dist as rdist
 from .. import ops
 
 __all__ = ['train_rlvi']
@@ -42,9 +43,18 @@ def train_rlvi(train_loader, model, optimizer,
 
     residuals, weights: caller-owned fp32 vectors of len(train_dataset) on DEVICE, mutated in
     place.  Returns (train_acc, threshold); threshold comes back unchanged while `overfit` is
-    False and as a 0-dim device tensor once truncation has run (as in the reference)."""
+    False and as a 0-dim device tensor once truncation has run (as in the reference).
+
+    Under an initialised torch.distributed group (one process per GPU, the loader sharded over
+    the ranks, the model wrapped in DistributedDataParallel) nothing changes for the caller:
+    every rank streams its own rows -- DDP's gradient averaging over equal shards turns the local
+    1/B into the single-device 1/B_global --, the residuals of the rows each rank visited are
+    exchanged once before the E-step, every rank runs the E-step / threshold on the identical
+    vector, and (train_acc, threshold) come back identical on every rank."""
     train_total = 0
     ws = ops.workspace(weights.device, weights.shape[0], 0)
+    world = rdist.world_size()
+    visited, sizes = [], []
 
     for (images, labels, indexes) in train_loader:
         images = images.to(weights.device, non_blocking=True)
@@ -52,21 +62,38 @@ def train_rlvi(train_loader, model, optimizer,
         indexes = indexes.to(weights.device, non_blocking=True)
 
         logits = model(images)
+        inv_scale = None                                       # 1 / B
+        if world > 1:
+            visited.append(indexes)
+            sizes.append(int(labels.shape[0]))
+            if rdist.ragged():                                 # unequal shards: world / B_global
+                inv_scale = world / rdist.global_batch(labels.shape[0])
         # reference :85,:89-94 and the backward of :96 in ONE fused launch over the logits:
         # top-1, per-sample CE, residuals[indexes] = loss, weights[indexes] gather, weighted
         # mean and d(loss)/d(logits); the batch scalars accumulate on the device
         _, grad = ops.mstep_fwd_bwd(logits.detach(), labels, indexes, weights,
-                                    residuals.detach(), accumulate=True, ws=ws)
+                                    residuals.detach(), inv_scale=inv_scale, accumulate=True, ws=ws)
         train_total += 1
 
         optimizer.zero_grad()
         logits.backward(grad)          # == loss.backward() of the reference (:96)
         optimizer.step()
 
+    if world > 1:
+        if not rdist.ragged():
+            rdist.check_equal_shards(sizes)
+        if visited:
+            rdist.exchange_residuals(residuals.detach(), torch.cat(visited))
+
     # reference :99-103 plus the reduction of the accumulated top-1 percentages (:86-87,:105):
     # E-step, optional truncation and the epoch scalars in one cooperative launch (+ threshold)
     threshold, out = ops.epoch_end(residuals.detach(), weights, overfit=overfit,
                                    threshold=threshold, batches=train_total, ws=ws)
+    if world > 1 and out is not None:
+        rdist.mean_scalars(out[:2])                            # per-rank means over equal shards
 
-    train_acc = float(out[1]) if train_total else float("nan")
+    train_acc = float(out[1]) if train_total else float("nan")     # (the one host sync of the epoch)
+    # out-of-range labels / indexes (the reference raises there), a cooperating launch whose
+    # workgroups could not all be resident, a fixed point that did not converge: never silent
+    ws.raise_on_status("train_rlvi")
     return train_acc, threshold

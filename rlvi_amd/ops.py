@@ -51,6 +51,19 @@ class Workspace:
                    "rlvi_workspace_status")
         return s.value
 
+    def clear_status(self):
+        _lib.check(_lib.load().rlvi_workspace_clear_status(self.ptr, _stream_ptr()),
+                   "rlvi_workspace_clear_status")
+
+    def raise_on_status(self, what, mask=_lib.ST_RANGE | _lib.ST_TIMEOUT | _lib.ST_NOCONV):
+        """Read the sticky device status (one 4-byte copy + stream sync) and raise RlviError on any
+        flag of `mask`; the flag is cleared first so that the caller can recover and go on."""
+        st = self.status()
+        if st & mask:
+            self.clear_status()
+            raise _lib.RlviError(f"{what}: device status {st}: {_lib.status_message(st & mask)}")
+        return st
+
 
 def debug_scratch_offset():
     """Byte offset of the workspace scratch area (where RLVI_TJ_DEBUG=1 leaves its stamps): the

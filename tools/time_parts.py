@@ -19,6 +19,8 @@ ap.add_argument("--n", type=int, default=0, help="E-step / threshold vector leng
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--tag", default="")
+ap.add_argument("--tune", action="append", default=[], help="NAME=VALUE knob (rlvi_tune_set); repeatable")
+ap.add_argument("--sweep", default="", help="NAME=v1,v2,...: time the leg once per value")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, C = a.rows, a.classes
@@ -67,29 +69,53 @@ with torch.cuda.stream(side):
                                                      None, None, ws.ptr, ops._stream_ptr()), "thr")
         elif a.what == "fused":
             ops.fused_em(logits[r], labels, pi, ws=ws, out=out, grad=grads[r], rows=rows, iters=iters)
-    for i in range(12):
-        leg(i)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
-        for i in range(a.steps):
+    from rlvi_amd import _lib as _L
+    for kv in a.tune:
+        k, v = kv.split("=")
+        _L.check(_L.load().rlvi_tune_set(k.encode(), int(v)), "rlvi_tune_set")
+
+    def time_leg():
+        for i in range(12):
             leg(i)
-    torch.cuda.synchronize()
-    best = 1e9
-    for rep in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side)
-        g.replay()
-        e1.record(side)
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / a.steps * 1e3)
-    extra = ""
-    if a.what in ("mstep", "mstep_fwd", "mstep_out"):
-        s = 2 if a.dtype == "bf16" else 4
-        byt = B * ((1 if a.what == "mstep_fwd" else 2) * C * s + 24)
-        extra = f" {byt / best / 1e3:8.1f} GB/s  frac {byt / best / 1e3 / 8000:.3f}"
-    if a.what in ("estep", "fused", "step"):
-        extra = f" iters {int(iters)}"
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(a.steps):
+                leg(i)
+        torch.cuda.synchronize()
+        best = 1e9
+        reps = []
+        for rep in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            torch.cuda.synchronize()
+            reps.append(e0.elapsed_time(e1) / a.steps * 1e3)
+            best = min(best, reps[-1])
+        print("   reps:", " ".join(f"{r:.2f}" for r in reps), flush=True)
+        return best
+
+    def describe(best):
+        extra = ""
+        if a.what in ("mstep", "mstep_fwd", "mstep_out"):
+            s = 2 if a.dtype == "bf16" else 4
+            byt = B * ((1 if a.what == "mstep_fwd" else 2) * C * s + 24)
+            extra = f" {byt / best / 1e3:8.1f} GB/s  frac {byt / best / 1e3 / 8000:.3f}"
+        if a.what in ("estep", "fused", "step"):
+            extra = f" iters {int(iters)}"
+        return extra
+
+    if a.sweep:
+        name, vals = a.sweep.split("=")
+        for v in vals.split(","):
+            _L.check(_L.load().rlvi_tune_set(name.encode(), int(v)), "rlvi_tune_set")
+            best = time_leg()
+            print(f"{a.tag or a.what:20s} {name}={v:>5s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch"
+                  f"{describe(best)}  status={ws.status()}", flush=True)
+        sys.exit(0)
+    best = time_leg()
+    extra = describe(best)
     if os.environ.get("RLVI_TJ_DEBUG"):
         import numpy as np
         from rlvi_amd import _lib
