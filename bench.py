@@ -21,7 +21,9 @@ on the launch stream, bracketed by barrier + synchronize, MAX over ranks.
 
 Extra objects on the JSON line: `roofline` (the streaming M-step kernel, algorithmic bytes
 2*C*4+24 per sample against 8 TB/s), `cpu_baseline` (the CPU oracle timed on this box's host
-cores), `parts` (per-kernel times), `parity` (this run's outputs checked against the oracle).
+cores), `parts` (per-kernel times: M-step cold / warm / at 4x the rows, E-step, threshold +
+truncation, the in-batch E+M composition), `parity` (this run's outputs checked against the
+oracle: loss, gradient, pi, iteration count, selection mask).
 """
 import argparse
 import json
@@ -184,8 +186,21 @@ def main():
             "pi_rel_max": float(np.max(np.abs(wg[big] - w_o[big]) / w_o[big])),
             "estep_iters": [it_gpu, int(it_o)],
         }
+        # selection mask (train_rlvi.py:41-49,:102-103, main.py:343): threshold + truncation on the
+        # GPU's own pi against the oracle on the same vector -- packed bits must be equal
+        w_thr = weights.clone()
+        thr_g, mask_g, kept_g = ops.threshold_truncate(w_thr, 0.0, want_mask=True, ws=ws)
+        torch.cuda.synchronize()
+        thr_o = O.false_negative_criterion(wg)
+        w_t = wg.copy()
+        mask_o = O.truncate(w_t, thr_o)
+        parity["mask_bits_equal"] = bool(np.array_equal(np.packbits(mask_g.cpu().numpy()), np.packbits(mask_o)))
+        parity["threshold"] = [float(thr_g), float(thr_o)]
+        parity["kept"] = [int(kept_g), int(mask_o.sum())]
         parity["ok"] = bool(parity["loss_rel"] <= 1e-5 and parity["grad_rel_fro"] <= 1e-5 and
-                            parity["pi_rel_max"] <= 1e-5 and it_gpu == it_o)
+                            parity["pi_rel_max"] <= 1e-5 and it_gpu == it_o and
+                            parity["mask_bits_equal"] and float(thr_g) == float(thr_o) and
+                            np.array_equal(w_thr.cpu().numpy(), w_t))
 
     # ---------------------------------------------------------------- timed regions
     def timed(fn, K, W, use_graph):
@@ -261,6 +276,58 @@ def main():
     # latency-bound E-step, each timed alone with HIP events on the launch stream
     ms_m = timed(mstep_only, K, W, use_graph) / K
     ms_e = timed(estep_only, K, W, use_graph) / K
+    extra = {}
+    if world == 1:
+        # single buffer pair: the block stays in the Infinity Cache between launches
+        def mstep_warm(i, ws):
+            ops.mstep_fwd_bwd(logits[0], labels, idx_local, weights, residuals, inv_scale=inv_scale,
+                              grad=grads[0], ws=ws, accumulate=True)
+        extra["mstep_warm_us"] = timed(mstep_warm, K, W, use_graph) / K * 1e3
+        # threshold + truncation over N samples (the epoch end once `overfit` is set; V4)
+        thr_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        w_thr = weights.clone()
+
+        def threshold_only(i, ws):
+            from rlvi_amd import _lib
+            _lib.check(_lib.load().rlvi_threshold_truncate_f32(ops._ptr(w_thr), N, 0.05, ops._ptr(thr_buf),
+                                                               None, None, ws.ptr, ops._stream_ptr()),
+                       "rlvi_threshold_truncate_f32")
+        extra["threshold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
+        extra["threshold_n"] = N
+        # in-batch E+M (V2): NLL pass -> E-step on this batch -> weighted loss + gradient
+        pi_b = torch.ones(B, dtype=torch.float32, device=dev)
+        rows_b = torch.empty(B, dtype=torch.float32, device=dev)
+        it_f = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def fused_only(i, ws):
+            r = i % ROTATE
+            ops.fused_em(logits[r], labels, pi_b, ws=ws, out=out, grad=grads[r], rows=rows_b, iters=it_f)
+        extra["fused_em_us"] = timed(fused_only, K, W, use_graph) / K * 1e3
+        extra["fused_em_iters"] = int(it_f.item())
+        # the M-step at 4x the rows (3 rotating pairs = 630 MB): the same kernel with the fixed
+        # launch / ramp-up share of a 10-us launch amortised -- separates steady-state bandwidth
+        # from ramp-up by measurement
+        if (B, C) == (65536, 100):
+            B4 = 4 * B
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(7)
+            big = [3.0 * torch.randn((B4, C), generator=gen, device=dev, dtype=torch.float32) for _ in range(3)]
+            gbig = [torch.empty((B4, C), dtype=torch.float32, device=dev) for _ in range(3)]
+            lab4 = labels.repeat(4)
+            idx4 = torch.randperm(B4, generator=gen, device=dev)
+            w4 = torch.rand(B4, generator=gen, device=dev)
+            r4 = torch.zeros(B4, device=dev)
+            ws4 = ops.Workspace(dev, B4, B4)
+
+            def mstep_big(i, _ws):
+                ops.mstep_fwd_bwd(big[i % 3], lab4, idx4, w4, r4, inv_scale=1.0 / B4, grad=gbig[i % 3],
+                                  ws=ws4, accumulate=True)
+            k4 = max(K // 4, 20)
+            ms4 = timed(mstep_big, k4, 6, use_graph) / k4
+            extra["mstep_4x_rows"] = B4
+            extra["mstep_4x_us"] = ms4 * 1e3
+            extra["mstep_4x_frac"] = (B4 * (2 * C * 4 + 24) / (ms4 * 1e-3)) / HBM_PEAK
+            del big, gbig
     bytes_per_sample = 2 * C * 4 + 24
     achieved = B * bytes_per_sample / (ms_m * 1e-3)
     # HBM bytes per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE x2 on gfx950 +
@@ -271,7 +338,7 @@ def main():
     if os.path.exists(tpath) and (B, C) == (65536, 100):
         traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
     result["roofline"] = {
-        "bound": "hbm", "kernel": "rlvi::mstep_tile_kernel<float,4,4,8>",
+        "bound": "hbm", "kernel": "rlvi::mstep_wave_kernel<float,4,4,7,4,true>",
         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": achieved / HBM_PEAK, "traffic": traffic,
         "traffic_unit": "bytes per launch (profiles/mstep_traffic.json)",
@@ -282,6 +349,7 @@ def main():
     result["parts"] = {"mstep_us": ms_m * 1e3, "estep_us": ms_e * 1e3,
                        "estep_iters": it_gpu, "estep_n": N,
                        "mstep_samples_per_s": B / (ms_m * 1e-3)}
+    result["parts"].update(extra)
     result["parity"] = parity
     st = ws.status()
     result["device_status"] = st

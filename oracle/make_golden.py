@@ -17,6 +17,7 @@ Golden sets:
   G6 online       update_weights_rlvi, CE          online-learning/main.py:45-58,:84-85
   G7 estimators   mean, pca, covariance            standard-learning/rlvi.py:23-65,:111-144
   G8 small-loss   usdnl.loss_fn, loss_coteaching   train_usdnl.py:16-27, train_coteaching.py:17-35
+  G9 top-1 ties   evaluate() on tied maxima        deep-learning/utils.py:48-62
 """
 import argparse
 import os
@@ -250,6 +251,29 @@ def gen_g4(ref):
         out[f"ep{ep}/b"] = model.bias.detach().numpy().copy()
         out[f"ep{ep}/overfit"] = np.array(overfit)
     out["orders"] = np.stack(orders)
+    # The same four epochs with model, data, residuals and weights in fp64: how far the reference's
+    # own fp32 run drifts from exact arithmetic.  The GPU tests accept a stated multiple of this.
+    model64 = torch.nn.Linear(D, C).double()
+    with torch.no_grad():
+        model64.weight.copy_(torch.from_numpy(W0).double())
+        model64.bias.copy_(torch.from_numpy(b0).double())
+    opt64 = torch.optim.SGD(model64.parameters(), lr=0.5, momentum=0.9)
+    res64 = torch.zeros(N, dtype=torch.float64)
+    w64 = torch.ones(N, dtype=torch.float64)
+    thr64 = 0
+    for ep, overfit in enumerate([False, False, True, True]):
+        perm = orders[ep]
+        loader = []
+        for s in range(0, N, B):
+            ix = perm[s:s + B]
+            loader.append((torch.from_numpy(X[ix]).double(), torch.from_numpy(y[ix]),
+                           torch.from_numpy(ix.astype(np.int64))))
+        model64.train()
+        _, thr64 = m.train_rlvi(loader, model64, opt64, res64, w64, overfit, thr64)
+        out[f"drift/ep{ep}/W"] = np.array(np.abs(model64.weight.detach().numpy() - out[f"ep{ep}/W"]).max())
+        out[f"drift/ep{ep}/residuals"] = np.array(np.abs(res64.detach().numpy() - out[f"ep{ep}/residuals"]).max())
+        out[f"drift/ep{ep}/weights"] = np.array(np.abs(w64.detach().numpy() - out[f"ep{ep}/weights"]).max())
+        out[f"drift/ep{ep}/threshold"] = np.array(abs(float(thr64) - float(out[f"ep{ep}/threshold"])))
     save("g4_epoch", **out)
 
 
@@ -392,7 +416,44 @@ def gen_g8(ref):
     save("g8_small_loss", **out)
 
 
-GROUPS = {"g7": gen_g7, "g8": gen_g8, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
+def gen_g9(ref):
+    """Top-1 on rows whose maximum is attained more than once: the reference's evaluate()
+    (deep-learning/utils.py:48-62: softmax -> torch.max -> eq) on logits handed through an identity
+    model.  Values are small integers / halves so that the bf16 path sees the same rows."""
+    import torch
+    sys.path.insert(0, os.path.join(ref, "deep-learning"))
+    import utils as ref_utils
+    rng = np.random.default_rng(9)
+    out, keys = {}, []
+    for C in (10, 100, 101):
+        B = 96
+        z = rng.integers(-6, 3, (B, C)).astype(np.float32)       # many exact ties below the maximum
+        labels = rng.integers(0, C, B).astype(np.int64)
+        for i in range(B):
+            kind = i % 6
+            cols = rng.choice(C, size=1 + (i % 4), replace=False)
+            z[i, cols] = 4.0 + 0.5 * (i % 3)                      # the tied maxima
+            if kind == 0: labels[i] = cols.min()                  # label = first maximum: hit
+            elif kind == 1: labels[i] = cols.max()                # label = last maximum: hit only if single
+            elif kind == 2: z[i, :] = 1.5; labels[i] = 0          # constant row, label first
+            elif kind == 3: z[i, :] = -2.0; labels[i] = C - 1     # constant row, label last
+            elif kind == 4: labels[i] = cols[0]                   # some maximum
+            # kind 5: random label
+        zt, yt = torch.from_numpy(z), torch.from_numpy(labels)
+        loader = [(zt[s:s + 32], yt[s:s + 32], None) for s in range(0, B, 32)]
+        acc = ref_utils.evaluate(loader, torch.nn.Identity())
+        _, pred = torch.max(torch.nn.functional.softmax(zt, dim=1).data, 1)
+        key = f"C{C}"
+        keys.append(key)
+        out[key + "/logits"] = z
+        out[key + "/labels"] = labels
+        out[key + "/acc"] = np.array(acc)
+        out[key + "/hit"] = (pred == yt).numpy()
+    out["cases"] = np.array(keys)
+    save("g9_top1_ties", **out)
+
+
+GROUPS = {"g9": gen_g9, "g7": gen_g7, "g8": gen_g8, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

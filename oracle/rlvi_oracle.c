@@ -49,10 +49,22 @@ void rlvi_oracle_set_threads(int n) {
  *   deep-learning/methods/train_rlvi.py:89  F.cross_entropy(reduction='none')
  *   deep-learning/utils.py:65-79            accuracy(): softmax -> topk -> eq
  * log-softmax is evaluated the way torch does it: (z - max) - log(sum exp).
- * Top-1 hit: the label's logit attains the row maximum.  When several columns tie
- * for the maximum the reference's topk picks one of them in an unspecified order,
- * so tied rows are "parity unpinned" (tests allow exactly those rows).
+ * Top-1 hit: the label is the FIRST column that attains the row maximum -- exactly one
+ * column of a row can be a hit.  That is the order of torch.max / argmax, which the
+ * reference's evaluate() uses (deep-learning/utils.py:57-58); accuracy()'s topk picks one of
+ * several tied columns in an unspecified order (utils.py:70), so for train_acc the WHICH is
+ * "parity unpinned", the HOW MANY (one) is not.  The kernels use the same rule as here.
+ * (Both reference paths look at softmax(logits); columns whose logits differ but whose
+ *  fp32 softmax values coincide are not reproduced.)
  * ------------------------------------------------------------------------- */
+static int first_max_is(const float *z, int64_t C, int64_t y, float m) {
+    (void)C;
+    if (z[y] != m) return 0;
+    for (int64_t c = 0; c < y; ++c)
+        if (z[c] == m) return 0;
+    return 1;
+}
+
 static inline void row_stats_f32(const float *z, int64_t C, float *m_out,
                                  float *logs_out, int64_t *amax_out) {
     float m = z[0];
@@ -77,7 +89,7 @@ void rlvi_oracle_nll_rows_f32(const float *logits, int64_t ld,
         row_stats_f32(z, C, &m, &logs, &am);
         const int64_t y = labels[i];
         loss[i] = -((z[y] - m) - logs);
-        if (hit) hit[i] = (z[y] == m);
+        if (hit) hit[i] = first_max_is(z, C, y, m);
     }
 }
 
@@ -117,7 +129,7 @@ int rlvi_oracle_mstep_f32(const float *logits, int64_t ld,
         const float pi = weights[idx[i]];      /* :92  gather (lagged pi) */
         lrow[i] = li;
         acc += (double)(li * pi);              /* :93 */
-        hits += (z[y] == m);
+        hits += first_max_is(z, C, y, m);
         if (grad) {
             const float g = pi * invB;
             float *gr = grad + i * ldg;

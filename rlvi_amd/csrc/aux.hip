@@ -157,13 +157,11 @@ extern "C" int rlvi_linreg_losses_f64(const double *X, const double *y, const do
     double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
     int nb = (int)((n + 3) / 4);
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(linreg_resid_kernel, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d,
-                       losses, part);
+    int rc = launch(linreg_resid_kernel, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d, losses, part);
+    if (rc != 0) return rc;
     int nb2 = (int)((n + 255) / 256);
     if (nb2 > 256) nb2 = 256;
-    hipLaunchKernelGGL(linreg_scale_kernel, dim3(nb2), dim3(256), 0, st, losses, n, part, nb,
-                       sigma2_out);
-    return (int)hipGetLastError();
+    return launch(linreg_scale_kernel, dim3(nb2), dim3(256), 0, st, losses, n, part, nb, sigma2_out);
 }
 
 extern "C" int rlvi_logistic_nll_f64(const double *X, const double *w, double b, int64_t n,
@@ -172,7 +170,6 @@ extern "C" int rlvi_logistic_nll_f64(const double *X, const double *w, double b,
     if (n <= 0 || d <= 0) return RLVI_E_SHAPE;
     int nb = (int)((n + 3) / 4);
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(logistic_nll_kernel, dim3(nb), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), X, w, b, n, d, losses);
-    return (int)hipGetLastError();
+    return launch(logistic_nll_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), X, w, b,
+                  n, d, losses);
 }

@@ -246,8 +246,8 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
         const float logs = logf(s);
         const float li = logs - (zy - m);   // == -((z_y - max) - log(sum exp)), as torch evaluates it
 
-        if (grad != nullptr && row_ok) {
-            const float gs = pi * inv_scale;
+        if (grad != nullptr && valid) {
+            const float gs = row_ok ? pi * inv_scale : 0.0f;   // a rejected row gets a zero gradient row
             const float inv_s = gs / s;
             T *grow = grad + rr * ldg;
 #pragma unroll
@@ -265,237 +265,31 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
                 }
             }
         }
+        // top-1: the label is a hit when it is the FIRST column that attains the row maximum
+        // (torch.max order, deep-learning/utils.py:58); two exact maxima put at least 2.0 into the
+        // sum, so the exact check (a second read of the row) runs only for waves that hold such a row
+        bool hit = zy == m;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit && s >= 2.0f) != 0, 0)) {
+            int earlier = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int col = (k * G + g) * V;
+                float z[V];
+                VecIO<T, V>::load(zrow + (live[k] ? col : g * V), z);
+#pragma unroll
+                for (int j = 0; j < V; ++j) earlier += (live[k] && z[j] == m && col + j < y) ? 1 : 0;
+            }
+            earlier = group_allreduce<G>(earlier, FAdd());
+            hit = hit && earlier == 0;
+        }
         if (g == 0 && row_ok) {
             if (residuals != nullptr) residuals[ix] = li;
             acc += li * pi;
-            hits += (zy == m) ? 1.0f : 0.0f;   // top-1: the label attains the row maximum
+            hits += hit ? 1.0f : 0.0f;
         }
     }
 
     // block partials -> workspace (fixed order: deterministic)
-    double a = wave_sum((double)acc);
-    double h = wave_sum((double)hits);
-    __shared__ double sh[2 * MSTEP_WAVES];
-    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = h; }
-    if (bad) atomicOr(status, RLVI_ST_RANGE);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0.0, th = 0.0;
-#pragma unroll
-        for (int w = 0; w < MSTEP_WAVES; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
-        write_partial(part, ta, th, inv_scale, inv_rows100, accum);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Tile form (dense rows, ld == C): the workgroup streams a tile of TR = 256/G rows through LDS.
-//   A  flat, fully coalesced 16-B/lane nontemporal loads of the tile (whole 128-B lines per
-//      wave instruction whatever C is) -> LDS; one thread per row fetches label, index, pi
-//   B  rows are processed out of LDS by G-lane groups exactly as in the register form; the
-//      gradient is written back into the tile in place
-//   C  flat nontemporal 16-B/lane stores of the tile to grad
-// Fragment-shaped global accesses (64/G row segments per instruction) keep the texture
-// addresser 2x busier for the same traffic and forbid `nt` (every line is touched by two
-// instructions); the flat form is what the copy ceiling is measured with.
-// ---------------------------------------------------------------------------------------
-#ifndef RLVI_MSTEP_MINWAVES
-#define RLVI_MSTEP_MINWAVES 1
-#endif
-template <typename T, int V, int G, int KMAX>
-__global__ __launch_bounds__(MSTEP_THREADS, RLVI_MSTEP_MINWAVES) void mstep_tile_kernel(
-    const T *__restrict__ logits, const int64_t *__restrict__ labels,
-    const int64_t *__restrict__ idx, const float *__restrict__ weights,
-    float *__restrict__ residuals, int64_t N, int64_t B, int C, int kact, float inv_scale,
-    T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status, int accum,
-    double inv_rows100) {
-    constexpr int TR = MSTEP_THREADS / G;          // rows per tile
-    constexpr int R = WAVE / G;                    // rows per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t tile_bytes = (size_t)TR * C * sizeof(T);       // multiple of 16 (host-checked)
-    T *tile = reinterpret_cast<T *>(smem);
-    int64_t *s_ix = reinterpret_cast<int64_t *>(smem + tile_bytes);
-    float *s_pi = reinterpret_cast<float *>(s_ix + TR);
-    int *s_y = reinterpret_cast<int *>(s_pi + TR);
-    T *pad = reinterpret_cast<T *>(s_y + TR);                   // 16 bytes of -inf
-    vu4 *tile16 = reinterpret_cast<vu4 *>(smem);
-    if (threadIdx.x < 16 / sizeof(T)) {
-        float ninf[1] = {-__builtin_inff()};
-        VecIO<T, 1>::store(pad + threadIdx.x, ninf);
-    }
-
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
-    const int wave = tid / WAVE;
-    const int g = lane & (G - 1);
-    const int sub = lane / G;
-    const float NEG_INF = -__builtin_inff();
-    const int nchunk = (int)(tile_bytes / 16);
-    const int64_t ntiles = (B + TR - 1) / TR;
-
-    float acc = 0.0f, hits = 0.0f;
-    bool bad = false;
-
-    // Software pipeline over this workgroup's tiles: the global loads of tile t+grid are issued
-    // right after tile t has been copied to LDS, so they fly during phases B and C of tile t.
-    // 16-byte chunks of the tile per thread: rows of K*V elements on G lanes, TR = 256/G rows
-    constexpr int SK = (KMAX * V * (int)sizeof(T) + 15) / 16;
-    vu4 stage[SK];
-    int64_t y64 = 0, ix = 0;
-    auto issue_tile = [&](int64_t tt) {
-        // per-row scalars first (they return ahead of the tile data), then the tile, branch-free
-        const int64_t rb = tt * TR;
-        const int64_t myrow = rb + (tid < TR ? tid : TR - 1);
-        y64 = labels[myrow];
-        ix = (idx != nullptr ? idx : labels)[myrow];
-        const vu4 *src = reinterpret_cast<const vu4 *>(logits + rb * C);
-#pragma unroll
-        for (int c = 0; c < SK; ++c) {
-            int i = c * MSTEP_THREADS + tid;
-            i = i < nchunk ? i : nchunk - 1;             // tail lanes re-read the last chunk
-            stage[c] = __builtin_nontemporal_load(src + i);
-        }
-    };
-    auto is_full = [&](int64_t tt) { return tt < ntiles && (tt + 1) * TR <= B; };
-    if (is_full(blockIdx.x)) issue_tile(blockIdx.x);
-
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t row_base = t * TR;
-        const int rows_here = (int)((B - row_base) < TR ? (B - row_base) : TR);
-        const T *gsrc = logits + row_base * C;
-        // ---- A
-        if (rows_here == TR) {
-            const int64_t myrow = row_base + (tid < TR ? tid : TR - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            ix = idx != nullptr ? ix : myrow;
-            bool okrow = true;
-            if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
-            if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
-            const float pi = weights != nullptr ? weights[ix] : 1.0f;   // no weights: plain CE
-            __builtin_amdgcn_sched_barrier(0);
-            if (tid < TR) {
-                s_ix[tid] = ix;
-                s_pi[tid] = pi;
-                s_y[tid] = okrow ? (int)y64 : -1;
-                bad = bad || !okrow;
-            }
-#pragma unroll
-            for (int c = 0; c < SK; ++c) {
-                const int i = c * MSTEP_THREADS + tid;
-                if (i < nchunk) tile16[i] = stage[c];
-            }
-            if (is_full(t + gridDim.x)) issue_tile(t + gridDim.x);      // prefetch the next tile
-        } else {
-            // ragged last tile: element-granular copy (never reads past the tensor)
-            const int64_t myrow = row_base + (tid < rows_here ? tid : rows_here - 1);
-            y64 = labels[myrow];
-            ix = idx != nullptr ? idx[myrow] : myrow;
-            bool okrow = true;
-            if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
-            if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
-            const float pi = weights != nullptr ? weights[ix] : 1.0f;   // no weights: plain CE
-            if (tid < rows_here) {
-                s_ix[tid] = ix;
-                s_pi[tid] = pi;
-                s_y[tid] = okrow ? (int)y64 : -1;
-                bad = bad || !okrow;
-            }
-#pragma unroll 1
-            for (int e = tid; e < rows_here * C; e += MSTEP_THREADS) tile[e] = gsrc[e];
-        }
-        __syncthreads();
-
-        // ---- B: one lane group per row, out of LDS
-        {
-            const int r_raw = wave * R + sub;
-            const bool valid = r_raw < rows_here;
-            const int r = valid ? r_raw : rows_here - 1;
-            T *zrow = tile + (size_t)r * C;
-            const int ys = s_y[r];
-            const bool row_ok = valid && ys >= 0;
-            const int y = ys >= 0 ? ys : 0;
-            const float pi = s_pi[r];
-            float zy;
-            {
-                float tt[1];
-                VecIO<T, 1>::load(zrow + y, tt);
-                zy = tt[0];
-            }
-            // unused vector slots of a lane read a 16-byte pad of -inf: no per-element masking
-            float v[KMAX][V];
-            bool live[KMAX];
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int col = (k * G + g) * V;
-                live[k] = k < kact && col < C;
-                VecIO<T, V>::load(live[k] ? zrow + col : pad, v[k]);
-            }
-            float m = NEG_INF;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-                for (int j = 0; j < V; ++j) m = fmaxf(m, v[k][j]);
-            m = group_max<G>(m);
-            float s = 0.0f;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const float e = mexp(v[k][j] - m);
-                    v[k][j] = e;
-                    s += e;
-                }
-            s = group_sum<G>(s);
-            const float logs = logf(s);
-            const float li = logs - (zy - m);
-            if (grad != nullptr) {
-                const float gs = pi * inv_scale;
-                const float inv_s = gs / s;
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    const int col = (k * G + g) * V;
-                    if (live[k] && valid) {
-                        float o[V];
-#pragma unroll
-                        for (int j = 0; j < V; ++j) {
-                            o[j] = v[k][j] * inv_s;
-                            if (sizeof(T) != 4 && col + j == y) o[j] -= gs;
-                        }
-                        VecIO<T, V>::store(zrow + col, o);     // in place, same lane that read it
-                    }
-                }
-                if (sizeof(T) == 4 && g == 0 && valid) {
-                    // -onehot term: one read-modify-write of the label entry, ordered behind
-                    // this wave's vector stores (LDS operations of a wave complete in order)
-                    float *zf = reinterpret_cast<float *>(zrow);
-                    zf[y] = zf[y] - gs;
-                }
-            }
-            if (g == 0 && row_ok) {
-                if (residuals != nullptr) residuals[s_ix[r]] = li;
-                acc += li * pi;
-                hits += (zy == m) ? 1.0f : 0.0f;
-            }
-        }
-
-        // ---- C: flat store of the gradient tile
-        if (grad != nullptr) {
-            __syncthreads();
-            T *gdst = grad + row_base * C;
-            if (rows_here == TR) {
-#pragma unroll
-                for (int c = 0; c < SK; ++c) {
-                    const int i = c * MSTEP_THREADS + tid;
-                    if (i < nchunk)
-                        __builtin_nontemporal_store(tile16[i], reinterpret_cast<vu4 *>(gdst) + i);
-                }
-            } else {
-#pragma unroll 1
-                for (int e = tid; e < rows_here * C; e += MSTEP_THREADS) gdst[e] = tile[e];
-            }
-        }
-        __syncthreads();      // the tile is rewritten by the next iteration
-    }
-
     double a = wave_sum((double)acc);
     double h = wave_sum((double)hits);
     __shared__ double sh[2 * MSTEP_WAVES];
@@ -813,11 +607,10 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
                         int kact, float inv_scale, T *grad, int64_t ldg, float *out, void *ws,
                         hipStream_t st) {
     constexpr int R = WAVE / G;
-    constexpr int TR = MSTEP_THREADS / G;
     constexpr int WPB = 4;                          // waves per workgroup of the wave-tile form
     const int cus = device_info().cus;
-    // form: 2 = wave tiles (LDS-DMA, no barriers), 1 = workgroup tiles, 0 = register rows
-    const int form = tune_get("RLVI_MSTEP_FORM", 2);
+    // form: 1 = wave tiles through LDS (dense rows), 0 = register rows everywhere
+    const int form = tune_get("RLVI_MSTEP_FORM", 1);
     char *base = static_cast<char *>(ws);
     double *part = reinterpret_cast<double *>(base + WS_PART_OFF);
     int32_t *status = reinterpret_cast<int32_t *>(base);
@@ -826,14 +619,12 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
     const bool flat16 = ld == C && (grad == nullptr || ldg == C) &&
                         ((uintptr_t)logits % 16) == 0 && ((uintptr_t)grad % 16) == 0;
     const size_t wtile_bytes = (size_t)R * C * sizeof(T);
-    const size_t tile_bytes = (size_t)TR * C * sizeof(T);
     constexpr size_t SKB = (size_t)((KMAX * V * sizeof(T) + 15) / 16);
     const bool dense_wave = flat16 && wtile_bytes % 16 == 0 && wtile_bytes / 16 <= SKB * WAVE;
-    const bool dense_tile = flat16 && tile_bytes % 16 == 0 && (tile_bytes + 15) / 16 <= SKB * MSTEP_THREADS;
     int64_t nb;
     int rc;
     const int64_t nfull = B / R;
-    if (dense_wave && form >= 2 && nfull > 0) {
+    if (dense_wave && form >= 1 && nfull > 0) {
         // `wpc` waves per CU stride over the R-row tiles (one tile each at the bench size)
         const int wpc = tune_get("RLVI_MSTEP_WPC", 16);
         nb = (nfull + WPB - 1) / WPB;
@@ -857,16 +648,6 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
                         residuals, N, B - done, C, kact, inv_scale, grad != nullptr ? grad + done * ldg : grad,
                         ldg, part, status, 1, inv_rows100, done);
         }
-    } else if (dense_tile && form >= 1) {
-        // three workgroups per CU, looping over the tiles
-        nb = (B + TR - 1) / TR;
-        const int tile_blocks = tune_get("RLVI_MSTEP_BLOCKS", 3 * cus);
-        if (nb > tile_blocks) nb = tile_blocks;
-        if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
-        const size_t lds = tile_bytes + (size_t)TR * 16 + 16;
-        rc = launch(mstep_tile_kernel<T, V, G, KMAX>, dim3((unsigned)nb), dim3(MSTEP_THREADS), lds, st,
-                    logits, labels, idx, weights, residuals, N, B, C, kact, inv_scale, grad, part,
-                    status, accum, inv_rows100);
     } else {
         const int max_blocks = tune_get("RLVI_MSTEP_BLOCKS", MSTEP_MAX_BLOCKS);
         const int64_t rows_per_block = (int64_t)MSTEP_WAVES * R;

@@ -247,9 +247,12 @@ __device__ __forceinline__ void reduce_partials(double *__restrict__ part, int n
     }
 }
 
-// Order-preserving key of an fp32 value (ascending value <=> ascending unsigned key).
+// Order-preserving key of an fp32 value (ascending value <=> ascending unsigned key).  Every NaN,
+// whatever its sign bit (0xFFC00000 is the x86 default and what inf - inf gives), takes the
+// largest key: NaN orders last, as numpy's argsort and torch.sort place it.
 __device__ __forceinline__ uint32_t f32_key(float f) {
     uint32_t b = __float_as_uint(f);
+    if (f != f) return 0xFFFFFFFFu;
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 __device__ __forceinline__ float key_f32(uint32_t k) {

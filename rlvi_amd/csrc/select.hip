@@ -97,7 +97,6 @@ extern "C" int rlvi_select_smallest_f32(const float *loss, int64_t n, int64_t k,
     if (n >= (int64_t)1 << 31) return RLVI_E_LIMIT;
     if (((uintptr_t)loss & 3) || ((uintptr_t)mask_w & 3)) return RLVI_E_ALIGN;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(select_smallest_kernel, dim3(1), dim3(SEL_BLOCK), 0,
-                       static_cast<hipStream_t>(stream), loss, n, k, mask_w);
-    return (int)hipGetLastError();
+    return launch(select_smallest_kernel, dim3(1), dim3(SEL_BLOCK), 0, static_cast<hipStream_t>(stream),
+                  loss, n, k, mask_w);
 }

@@ -263,24 +263,33 @@ __device__ __forceinline__ bool thq_load(gu64 *p, uint32_t tag, uint32_t &cnt, u
 
 // Totals of the per-workgroup histograms sh.h over the G workgroups, back into sh.h (identical
 // on every workgroup).  All threads call; returns false after a timeout (sh.dead set).
+#define THQ_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
 __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bufB, uint32_t tag,
                                              int xstep, int G, WsHeader *hdr,
-                                             unsigned long long spin_ticks) {
+                                             unsigned long long spin_ticks, unsigned long long *dbg,
+                                             int &dbgi) {
     if (G == 1) return true;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int b = (int)blockIdx.x;
     gu64 *A = bufA + (size_t)(xstep & 1) * THR_BINS * MAX_COOP_WG * XCHG4_GRANULES;
     gu64 *B = bufB + (size_t)(xstep & 1) * XCHG4B_REPLICAS * THR_BINS * XCHG4_GRANULES;
     // ---- stage A: thread t publishes this workgroup's record of bin t
-    thq_store(A + ((size_t)tid * MAX_COOP_WG + b) * XCHG4_GRANULES, tag, sh.h.cnt[tid], sh.h.mn[tid],
+    // (layout [workgroup][bin]: the writer's 8 KiB are contiguous -- whole lines per store
+    //  instruction; the one-time scattered access is on the reducers' read side)
+    thq_store(A + ((size_t)b * THR_BINS + tid) * XCHG4_GRANULES, tag, sh.h.cnt[tid], sh.h.mn[tid],
               sh.h.sum[tid]);
-    // ---- stage B: workgroup b adds the records of bins b, b + G, ... (thread w = workgroup w)
-    for (int bin = b; bin < THR_BINS; bin += G) {
+    THQ_STAMP();   // stage A stored
+    // ---- stage B: workgroup b adds the records of its 256 / G bins (G is 64, 128 or 256): G / 64
+    // waves per bin, lane = publishing workgroup, all bins of this workgroup gathered at once
+    {
+        const int wpb = G >> 6;                              // waves per bin
+        const int bin = b + G * (wave / wpb);                // this wave's bin
+        const int wg = (wave % wpb) * WAVE + lane;           // the workgroup whose record this lane reads
         uint32_t c = 0, mn = 0xFFFFFFFFu;
         unsigned long long sm = 0ull;
         bool timeout = false;
-        if (tid < G) {
-            gu64 *p = A + ((size_t)bin * MAX_COOP_WG + tid) * XCHG4_GRANULES;
+        {
+            gu64 *p = A + ((size_t)wg * THR_BINS + bin) * XCHG4_GRANULES;
             const unsigned long long t0 = wall_clock64();
             for (unsigned spin = 0;; ++spin) {
                 if (thq_load(p, tag, c, mn, sm)) break;
@@ -288,34 +297,36 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
             }
         }
         if (timeout) { c = 0; mn = 0xFFFFFFFFu; sm = 0ull; sh.dead = 1; }
+        THQ_STAMP();   // gathered
         unsigned long long tc = wave_sum((unsigned long long)c);
         unsigned long long ts = wave_sum(sm);
         uint32_t tm = (uint32_t)wave_min((unsigned long long)mn);
-        if (lane == 0) { sh.wcnt[wave] = tc; sh.wsum[wave] = ts; sh.wmin[wave] = tm; }
-        __syncthreads();
-        if (wave == 0) {
+        if (wpb > 1) {
+            if (lane == 0) { sh.wcnt[wave] = tc; sh.wsum[wave] = ts; sh.wmin[wave] = tm; }
+            __syncthreads();
             tc = 0ull; ts = 0ull; tm = 0xFFFFFFFFu;
-#pragma unroll
-            for (int w = 0; w < THQ_NW; ++w) {      // fixed order (integers: any order gives these bits)
+            const int w0 = wave / wpb * wpb;
+            for (int w = w0; w < w0 + wpb; ++w) {            // fixed order (integers: any order gives these bits)
                 tc += sh.wcnt[w]; ts += sh.wsum[w]; tm = sh.wmin[w] < tm ? sh.wmin[w] : tm;
             }
-            // lane l stores granule l & 3 of replica l >> 2: one 8-byte store per lane
-            if (lane < XCHG4_GRANULES * XCHG4B_REPLICAS && sh.dead == 0) {
-                const int gq = lane & 3, rep = lane >> 2;
-                const uint32_t v = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
-                                                                           : (uint32_t)(ts >> 32);
-                __hip_atomic_store(B + ((size_t)rep * THR_BINS + bin) * XCHG4_GRANULES + gq,
-                                   ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
-        __syncthreads();                             // wcnt / wsum / wmin are rewritten by the next bin
+        // the first wave of a bin publishes its total: lane l stores granule l & 3 of replica l >> 2
+        if (wave % wpb == 0 && lane < XCHG4_GRANULES * XCHG4B_REPLICAS && sh.dead == 0) {
+            const int gq = lane & 3, rep = lane >> 2;
+            const uint32_t v = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
+                                                                       : (uint32_t)(ts >> 32);
+            __hip_atomic_store(B + ((size_t)rep * THR_BINS + bin) * XCHG4_GRANULES + gq,
+                               ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        THQ_STAMP();   // published
     }
     // ---- everybody: the 256 totals (thread t = bin t), replica blockIdx % 8
     {
         uint32_t c = 0, mn = 0xFFFFFFFFu;
         unsigned long long sm = 0ull;
         bool timeout = false;
+        __syncthreads();                                     // (sh.dead of this step, w* free again)
         if (sh.dead == 0) {
             gu64 *p = B + ((size_t)(b & (XCHG4B_REPLICAS - 1)) * THR_BINS + tid) * XCHG4_GRANULES;
             const unsigned long long t0 = wall_clock64();
@@ -328,6 +339,7 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
         sh.h.cnt[tid] = c; sh.h.mn[tid] = mn; sh.h.sum[tid] = sm;
     }
     __syncthreads();
+    THQ_STAMP();   // totals in
     if (sh.dead != 0) {
         if (tid == 0) atomicOr(&hdr->status, RLVI_ST_TIMEOUT);
         return false;
@@ -339,8 +351,10 @@ template <int E, bool TRUNC>
 __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     float *__restrict__ w, int64_t N, float alpha, float *__restrict__ thr_io,
     uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out, int32_t *__restrict__ fallback,
-    void *ws) {
+    void *ws, unsigned long long *__restrict__ dbg) {
     __shared__ ThqShared sh;
+    int dbgi = 0;
+    THQ_STAMP();
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int b = (int)blockIdx.x, G = (int)gridDim.x;
     char *wsb = static_cast<char *>(ws);
@@ -368,6 +382,7 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         k[j] = have[j] ? __float_as_uint(w[i]) : 0u;
         if (have[j] && k[j] > 0x3F800000u) { ++nbad; have[j] = false; }   // NaN, negative, -0.0, > 1
     }
+    THQ_STAMP();   // slice loaded
 
     unsigned long long S_base = 0ull, cnt_base = 0ull;   // sum / count of the keys above the current range
     uint32_t above = 0xFFFFFFFFu;                        // smallest key above the current range
@@ -397,66 +412,91 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         }
         if (level == 0 && nbad != 0u) atomicAdd(&sh.h.cnt[THR_BINS - 1], nbad);   // no valid key has top byte 0xFF
         __syncthreads();
-        ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks);
+        THQ_STAMP();   // histogram built
+        ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
         ++tag; ++xstep;
-        if (!ok) break;
-        if (level == 0 && sh.h.cnt[THR_BINS - 1] != 0u) {   // out of [0, 1]: the generic kernel takes over
-            if (b == 0 && tid == 0) *fallback = 1;
-            ok = false;
+        if (!ok) {
+            if (level == 0 && b == 0 && tid == 0) *fallback = 0;
             break;
         }
-        // ---- suffix scan over the bins: thread t holds T(t) = S_base + sum of bins >= t
-        unsigned long long sfx = sh.h.sum[tid], cfx = (unsigned long long)sh.h.cnt[tid];
-        uint32_t mfx = sh.h.mn[tid];
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const unsigned long long os = __shfl_down(sfx, d, WAVE), oc = __shfl_down(cfx, d, WAVE);
-            const uint32_t om = __shfl_down(mfx, d, WAVE);
-            if (lane + d < WAVE) { sfx += os; cfx += oc; mfx = om < mfx ? om : mfx; }
-        }
-        if (lane == 0) { sh.wsum[wave] = sfx; sh.wcnt[wave] = cfx; sh.wmin[wave] = mfx; }
-        __syncthreads();
-#pragma unroll
-        for (int wv = 1; wv < THQ_NW; ++wv)
-            if (wave + wv < THQ_NW) {
-                sfx += sh.wsum[wave + wv]; cfx += sh.wcnt[wave + wv];
-                mfx = sh.wmin[wave + wv] < mfx ? sh.wmin[wave + wv] : mfx;
-            }
         if (level == 0) {
-            // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44): the total is T(0)
-            if (tid == 0) { sh.r_sum = sfx; sh.r_min = mfx; }
-            __syncthreads();
-            beta = (float)((double)sh.r_sum * (1.0 / 16777216.0)) * alpha;
-            gmin = sh.r_min;
-            __syncthreads();
+            // out of [0, 1]: the generic kernel (enqueued behind this one) takes over
+            const bool range_bad = sh.h.cnt[THR_BINS - 1] != 0u;
+            if (b == 0 && tid == 0) *fallback = range_bad ? 1 : 0;
+            if (range_bad) { ok = false; break; }
         }
-        // the predicate is monotone along the bins (T is non-increasing): b1 = number of bins that fail
-        const bool fits = pred(S_base + sfx);
-        const unsigned long long bal = __ballot(fits);
-        if (lane == 0) sh.wtrue[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t ntrue = 0;
+        // ---- wave 0: suffix sums T(t) = S_base + sum of bins >= t (lane l owns bins 4l..4l+3), the
+        // first bin b1 whose suffix fits (the predicate is monotone along the bins: T is non-increasing)
+        if (wave == 0) {
+            unsigned long long t4[4];
 #pragma unroll
-        for (int wv = 0; wv < THQ_NW; ++wv) ntrue += sh.wtrue[wv];
-        const int b1 = THR_BINS - (int)ntrue;             // first bin whose suffix fits (256: none)
+            for (int q = 0; q < 4; ++q) t4[q] = sh.h.sum[4 * lane + q];
+            t4[2] += t4[3]; t4[1] += t4[2]; t4[0] += t4[1];
+            unsigned long long sfx = t4[0];                       // sum of my bins and, below, of all higher lanes'
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const unsigned long long os = __shfl_down(sfx, d, WAVE);
+                if (lane + d < WAVE) sfx += os;
+            }
+            const unsigned long long higher = sfx - t4[0];        // bins of the lanes above mine
+            if (level == 0) {
+                // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44): the total is T(0)
+                const unsigned long long total = __shfl(sfx, 0, WAVE);
+                beta = (float)((double)total * (1.0 / 16777216.0)) * alpha;
+            }
+            int ntrue = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t4[q] += higher;                                  // T(4 lane + q) - S_base
+                ntrue += (int)__popcll(__ballot(pred(S_base + t4[q])));
+            }
+            const int b1w = THR_BINS - ntrue;                     // first bin whose suffix fits (256: none)
+            if (lane == (b1w >> 2) || (b1w == THR_BINS && lane == 0))
+                sh.r_sum = b1w == THR_BINS ? 0ull : t4[b1w & 3];
+            if (lane == 0) { sh.r_b1 = (uint32_t)b1w; sh.r_min = __float_as_uint(beta); }
+        }
+        __syncthreads();
+        const int b1 = (int)sh.r_b1;
+        if (level == 0) beta = __uint_as_float(sh.r_min);
         if (b1 == 0) {
             // every key of the range fits (only possible at level 0: a deeper range was entered
             // because it does NOT fit as a whole): count = N, threshold = smallest weight
+            uint32_t m0 = (uint32_t)wave_min((unsigned long long)sh.h.mn[tid]);
+            if (lane == 0) sh.wmin[wave] = m0;
+            __syncthreads();
+            gmin = sh.wmin[0];
+#pragma unroll
+            for (int wv = 1; wv < THQ_NW; ++wv) gmin = sh.wmin[wv] < gmin ? sh.wmin[wv] : gmin;
             all_inside = true;
             break;
         }
-        if (tid == b1 || (b1 == THR_BINS && tid == 0)) {
-            sh.r_sum = b1 == THR_BINS ? 0ull : sfx;
-            sh.r_cnt = b1 == THR_BINS ? 0ull : cfx;
-            sh.r_min = b1 == THR_BINS ? 0xFFFFFFFFu : mfx;
+        // count / smallest key of the bins >= b1 (masked block reductions), at level 0 the global minimum
+        {
+            const bool up = tid >= b1;
+            const unsigned long long cw = wave_sum(up ? (unsigned long long)sh.h.cnt[tid] : 0ull);
+            const uint32_t mw = (uint32_t)wave_min(up ? (unsigned long long)sh.h.mn[tid] : 0xFFFFFFFFull);
+            const uint32_t gw = level == 0 ? (uint32_t)wave_min((unsigned long long)sh.h.mn[tid]) : 0u;
+            if (lane == 0) { sh.wcnt[wave] = cw; sh.wmin[wave] = mw; sh.wtrue[wave] = gw; }
         }
         __syncthreads();
-        S_base += sh.r_sum;
-        cnt_base += sh.r_cnt;
-        above = sh.r_min < above ? sh.r_min : above;
-        prefix = (prefix << 8) | (uint32_t)(b1 - 1);
-        below_cnt = sh.h.cnt[b1 - 1];
-        __syncthreads();                                  // r_* and the histogram are rewritten by the next pass
+        {
+            unsigned long long cab = 0ull;
+            uint32_t mab = 0xFFFFFFFFu, g0 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int wv = 0; wv < THQ_NW; ++wv) {
+                cab += sh.wcnt[wv];
+                mab = sh.wmin[wv] < mab ? sh.wmin[wv] : mab;
+                g0 = sh.wtrue[wv] < g0 ? sh.wtrue[wv] : g0;
+            }
+            if (level == 0) gmin = g0;
+            S_base += sh.r_sum;
+            cnt_base += cab;
+            above = mab < above ? mab : above;
+            prefix = (prefix << 8) | (uint32_t)(b1 - 1);
+            below_cnt = sh.h.cnt[b1 - 1];
+        }
+        __syncthreads();                                  // r_*, w* and the histogram are rewritten by the next pass
+        THQ_STAMP();   // scan done
     }
 
     float thr = 0.0f;
@@ -500,13 +540,16 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
             const unsigned long long kw = wave_sum((unsigned long long)kept);
             if (lane == 0) atomicAdd(&sh.h.sum[0], kw);
             __syncthreads();
-            ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks);
+            ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
             ++tag; ++xstep;
             if (ok && b == 0 && tid == 0) *kept_out = (int64_t)sh.h.sum[0];
         }
     }
+    THQ_STAMP();   // truncated
     if (b == 0 && tid == 0) {
         if (ok) *thr_io = thr;
+        // (the generic kernel behind this one looks at the flag: 1 only when the range check failed)
+        if (dbg != nullptr) dbg[63] = (unsigned long long)dbgi;
         __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -526,41 +569,46 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
 // workgroups, handing over to the generic fp64 form (any range) by setting a flag the generic kernel
 // reads at its start -- both are enqueued, the second is a no-op when the first one did the work.
 // Larger: one workgroup, streaming.
-__global__ void threshold_flag_clear(int32_t *flag) { *flag = 0; }
-
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
                             int64_t *kept, void *ws, hipStream_t st) {
     int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
+    unsigned long long *dbg = tune_get("RLVI_THR_DEBUG", 0)
+                                  ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF + 256)
+                                  : nullptr;
     int rc = RLVI_E_LIMIT;
     bool launched = false;
-#define RLVI_THQ(E_)                                                                             \
+#define RLVI_THQ(E_, G_)                                                                         \
     do {                                                                                         \
         auto kern = threshold_radix_kernel<E_, TRUNC>;                                           \
-        int G = coop_cap(kern, THQ_BLOCK);                                                       \
-        if (G > MAX_COOP_WG) G = MAX_COOP_WG;                                                    \
-        const int64_t want = (N + THQ_BLOCK - 1) / THQ_BLOCK;     /* one key per thread is enough */ \
-        if (G > want) G = (int)want;                                                             \
-        if (G >= 1 && (N + G - 1) / G <= (int64_t)(E_) * THQ_BLOCK) {                            \
-            rc = launch(threshold_flag_clear, dim3(1), dim3(1), 0, st, flag);                    \
-            if (rc == 0)                                                                         \
-                rc = launch(kern, dim3((unsigned)G), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask, \
-                            kept, flag, ws);                                                     \
+        const int g_ = (G_);                                                                     \
+        if (!launched && (g_ == 1 || coop_cap(kern, THQ_BLOCK) >= g_) &&                           \
+            (N + g_ - 1) / g_ <= (int64_t)(E_) * THQ_BLOCK) {                                      \
+            rc = launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask,     \
+                        kept, flag, ws, dbg);                                                    \
             if (rc == 0)                                                                         \
                 rc = launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, \
                             thr, mask, kept, (const int32_t *)flag);                             \
             launched = true;                                                                     \
         }                                                                                        \
     } while (0)
-    const int64_t Lfull = (N + MAX_COOP_WG - 1) / MAX_COOP_WG;    // slice at the full width
+    // G = 1 (no exchange) up to 1024 keys; 64 workgroups (fewest participants per exchange) while a
+    // slice fits 8 keys per thread, then 128, then 256; every G > 1 only if the occupancy query says
+    // that many workgroups are co-resident on this device
     if (tune_get("RLVI_THR_RADIX", 1)) {
-        if (Lfull <= THQ_BLOCK * 1) RLVI_THQ(1);
-        else if (Lfull <= THQ_BLOCK * 2) RLVI_THQ(2);
-        else if (Lfull <= THQ_BLOCK * 4) RLVI_THQ(4);
-        else if (Lfull <= THQ_BLOCK * 8) RLVI_THQ(8);
-        else if (Lfull <= THQ_BLOCK * 16) RLVI_THQ(16);
-        else if (Lfull <= THQ_BLOCK * 32) RLVI_THQ(32);
-        if (!launched && N <= (int64_t)THQ_BLOCK * 32) RLVI_THQ(32);   // few co-resident workgroups: longer slices
+        const int force_g = tune_get("RLVI_THR_G", 0);
+        if (N <= 1024 && !force_g) RLVI_THQ(4, 1);
+        for (int G = 64; G <= 256; G *= 2) {
+            if (force_g && G != force_g) continue;
+            const int64_t L = (N + G - 1) / G;
+            if (L <= THQ_BLOCK * 1) RLVI_THQ(1, G);
+            else if (L <= THQ_BLOCK * 2) RLVI_THQ(2, G);
+            else if (L <= THQ_BLOCK * 4) RLVI_THQ(4, G);
+            else if (L <= THQ_BLOCK * 8) RLVI_THQ(8, G);
+            else if (G == 256 && L <= THQ_BLOCK * 16) RLVI_THQ(16, G);
+            else if (G == 256 && L <= THQ_BLOCK * 32) RLVI_THQ(32, G);
+        }
+        if (N <= 8192) RLVI_THQ(32, 1);          // (fewer than 64 co-resident workgroups: one workgroup)
     }
 #undef RLVI_THQ
     if (launched) return rc;

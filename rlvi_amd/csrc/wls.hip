@@ -158,9 +158,8 @@ extern "C" int rlvi_wls_solve_f64(const double *X, const double *y, const double
     if (nwg > WLS_MAX_WG) nwg = WLS_MAX_WG;
     double *partial = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_WLS_OFF);
     int32_t *status = reinterpret_cast<int32_t *>(ws);
-    hipLaunchKernelGGL(wls_gram_kernel, dim3(nwg), dim3(WLS_THREADS), 0, st, X, y, w, n, (int)d, dp,
-                       partial);
-    hipLaunchKernelGGL(wls_solve_kernel, dim3(1), dim3(64), 0, st, partial, nwg, (int)d, dp, theta,
-                       status);
-    return (int)hipGetLastError();
+    const int rc = launch(wls_gram_kernel, dim3(nwg), dim3(WLS_THREADS), 0, st, X, y, w, n, (int)d, dp,
+                          partial);
+    if (rc != 0) return rc;
+    return launch(wls_solve_kernel, dim3(1), dim3(64), 0, st, partial, nwg, (int)d, dp, theta, status);
 }

@@ -56,13 +56,21 @@ def run_g4_epochs(train_rlvi, device, rank, world, wrap=None):
     return states
 
 
+G4_DRIFT_MULT = 16.0      # accepted distance from G4 in units of the reference's own fp32-vs-fp64 drift
+
+
 def check_against_g4(states):
+    """G4 holds, next to the reference's fp32 outputs, how far they drift from the same epochs run in
+    fp64 (drift/*).  Accept G4_DRIFT_MULT of that drift plus one fp32 ulp of the largest value."""
     g = np.load(GOLDEN)
     for ep, st in enumerate(states):
-        np.testing.assert_allclose(st["W"], g[f"ep{ep}/W"], rtol=2e-4, atol=2e-5)
-        np.testing.assert_allclose(st["residuals"], g[f"ep{ep}/residuals"], rtol=1e-3, atol=2e-4)
-        np.testing.assert_allclose(st["weights"], g[f"ep{ep}/weights"], rtol=2e-3, atol=2e-4)
-        assert st["threshold"] == pytest.approx(float(g[f"ep{ep}/threshold"]), rel=2e-3, abs=1e-6)
+        for name in ("W", "residuals", "weights"):
+            ref = g[f"ep{ep}/{name}"]
+            tol = G4_DRIFT_MULT * float(g[f"drift/ep{ep}/{name}"]) + 1.2e-7 * float(np.abs(ref).max())
+            err = float(np.abs(st[name] - ref).max())
+            assert err <= tol, (ep, name, err, tol)
+        thr_tol = G4_DRIFT_MULT * max(float(g[f"drift/ep{ep}/threshold"]), float(g[f"drift/ep{ep}/weights"])) + 1.2e-7
+        assert abs(st["threshold"] - float(g[f"ep{ep}/threshold"])) <= thr_tol
         assert st["acc"] == pytest.approx(float(g[f"ep{ep}/train_acc"]), abs=1e-3)
 
 

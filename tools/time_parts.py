@@ -116,6 +116,13 @@ with torch.cuda.stream(side):
         sys.exit(0)
     best = time_leg()
     extra = describe(best)
+    if a.what == "thr" and any(t.startswith("RLVI_THR_DEBUG") for t in a.tune):
+        import numpy as np
+        off = ops.debug_scratch_offset() + 256
+        raw = ws.buf[off:off + 64 * 8].cpu().numpy().view(np.uint64)
+        n = int(raw[63])
+        st = raw[:n].astype(np.int64)
+        print("thr stamps (us since kernel start):", [round(float(x - st[0]) / 100.0, 2) for x in st])
     if os.environ.get("RLVI_TJ_DEBUG"):
         import numpy as np
         from rlvi_amd import _lib
