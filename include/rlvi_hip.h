@@ -49,7 +49,8 @@ extern "C" {
                               not all resident, e.g. beside another process's kernels): the launch left its
                               outputs -- pi, threshold -- as they were                */
 #define RLVI_ST_NOCONV  4  /* the trajectory E-step did not reach its fixed point (results invalid) */
-#define RLVI_ST_SINGULAR 8 /* weighted least squares: Gram matrix not positive definite (theta = NaN) */
+#define RLVI_ST_SINGULAR 8 /* weighted least squares: rank-deficient design; theta is the minimum-norm
+                              solution (what the reference's lstsq returns), NaN for non-finite data */
 
 int rlvi_abi_version(void);
 const char *rlvi_error_string(int code);
@@ -179,7 +180,8 @@ int rlvi_update_weights_online_f64(const double *losses, int64_t n, double tol, 
                                    double *out, int32_t *out_iters, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------
- * Dense X.theta contraction + per-sample NLL of the linear / logistic paths (fp64 MFMA).
+ * Per-sample NLL of the linear / logistic paths: the X.theta / X.w contraction on the fp64 matrix
+ * cores (v_mfma_f64_16x16x4_f64, 16 rows per wave; n*d is 15-20 k elements: launch-latency-bound).
  *   rlvi_linreg_losses_f64  rlvi.py:72-74 / :81-83: r=(y-X theta)^2, sigma2=w.r/sum(w),
  *                           losses=0.5 r/sigma2;  sigma2_out device fp64
  *   rlvi_logistic_nll_f64   online-learning/main.py:295-296,:84-85: -log sigmoid(X w + b)
@@ -188,7 +190,8 @@ int rlvi_update_weights_online_f64(const double *losses, int64_t n, double tol, 
 /* Weighted least squares theta = argmin sum_i w_i (y_i - x_i.theta)^2, the M-step of
  * linear_regression (standard-learning/rlvi.py:70-71,:79-80, scipy lstsq on diag(sqrt(w))-scaled
  * rows there): [X | y]^T W [X | y] on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), Cholesky +
- * triangular solves in one workgroup.  d <= 63, X of full column rank. */
+ * triangular solves in one workgroup; a rank-deficient design sets RLVI_ST_SINGULAR and gets the
+ * minimum-norm solution (Jacobi eigen-decomposition of the Gram matrix), as lstsq gives.  d <= 63. */
 int rlvi_wls_solve_f64(const double *X, const double *y, const double *w, int64_t n, int64_t d,
                        double *theta, void *ws, void *stream);
 int rlvi_linreg_losses_f64(const double *X, const double *y, const double *theta,

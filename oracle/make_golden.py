@@ -318,6 +318,18 @@ def gen_g5(ref):
         out[key + "/theta"] = theta
         out[key + "/outer"] = np.array(len(calls))
         out[key + "/w_last"] = calls[-1]
+    # rank-deficient design (two identical columns, one all-zero column): the reference's lstsq
+    # (rlvi.py:71,:80, LAPACK gelsd) returns the MINIMUM-NORM least-squares solution
+    X, y = synth.linreg_data(size=200, d=6, eps=0.2, nu=2.5, seed=4)
+    X = np.concatenate([X, X[:, 2:3], np.zeros((200, 1))], axis=1)
+    theta = ref_rlvi.linear_regression(X, y)
+    out["linreg_rankdef/X"] = X
+    out["linreg_rankdef/y"] = y
+    out["linreg_rankdef/theta"] = theta
+    from scipy.linalg import lstsq as _lstsq
+    wr = np.random.default_rng(5).random(200)
+    out["linreg_rankdef/w"] = wr
+    out["linreg_rankdef/theta_wls"] = _lstsq(np.sqrt(wr)[:, None] * X, np.sqrt(wr) * y)[0]
     # logistic regression: generate_data_logistic_regression-style 2-D data
     rng = np.random.default_rng(3)
     n = 200

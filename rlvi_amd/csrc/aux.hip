@@ -82,12 +82,37 @@ extern "C" int rlvi_fused_em_f32(const float *logits, int64_t ld, const int64_t 
 }
 
 // ---------------------------------------------------------------------------------------
-// fp64 X.theta + per-sample NLL.  One wave per row group; d is small (20 / 60), so the
-// contraction is a per-row dot product kept in fp64 FMA order-independent form (tree sum).
+// fp64 X.theta + per-sample NLL.  The contraction runs on the fp64 matrix cores, 16 rows per wave
+// (rows16_dot_mfma); a per-row wave dot product (tree sum) is kept as the measured alternative.
+// n*d is 15-20 k elements here: launch-latency-bound either way.
 // ---------------------------------------------------------------------------------------
 namespace rlvi {
 
+// X[row0 .. row0+15] . v on the fp64 matrix cores: the dense X.w / X.theta contraction of the
+// linear / logistic paths (standard-learning/rlvi.py:72,:81; online-learning/main.py:295) as
+// v_mfma_f64_16x16x4_f64 steps with A = a 16 x 4 panel of X and B = the 4 matching entries of v in every
+// column.  Operand maps as in wls.hip: lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// the results of a lane are D[row = (l>>4) + 4 r][col = l&15], all columns alike.  Lanes with
+// (l&15) < 4 return the dot product of row (l>>4) + 4 (l&15) (`mine` tells which), the others 0.
+typedef double aux_d4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double rows16_dot_mfma(const double *__restrict__ X, const double *__restrict__ v,
+                                                  int64_t row0, int64_t n, int64_t d, int &myrow) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t row = row0 + i;
+    aux_d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t k0 = 0; k0 < d; k0 += 4) {
+        const int64_t k = k0 + kk;
+        const double a = (row < n && k < d) ? X[row * d + k] : 0.0;
+        const double b = k < d ? v[k] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    myrow = i < 4 ? kk + 4 * i : -1;
+    return i == 0 ? acc[0] : i == 1 ? acc[1] : i == 2 ? acc[2] : acc[3];
+}
+
 // r_i = (y_i - x_i.theta)^2 -> losses; block partials of {w.r, sum w} -> part
+template <bool MFMA>
 __global__ __launch_bounds__(256) void linreg_resid_kernel(const double *__restrict__ X,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ theta,
@@ -97,15 +122,29 @@ __global__ __launch_bounds__(256) void linreg_resid_kernel(const double *__restr
                                                            double *__restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double num = 0.0, den = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
-        double p = 0.0;
-        for (int64_t j = lane; j < d; j += 64) p += X[i * d + j] * theta[j];
-        p = wave_sum(p);
-        const double r = (y[i] - p) * (y[i] - p);
-        if (lane == 0) {
-            losses[i] = r;
-            num += w[i] * r;
-            den += w[i];
+    if (MFMA) {
+        for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16; r0 < n; r0 += (int64_t)gridDim.x * 64) {
+            int myrow;
+            const double p = rows16_dot_mfma(X, theta, r0, n, d, myrow);
+            const int64_t i = r0 + myrow;
+            if (myrow >= 0 && i < n) {
+                const double r = (y[i] - p) * (y[i] - p);
+                losses[i] = r;
+                num += w[i] * r;
+                den += w[i];
+            }
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+            double p = 0.0;
+            for (int64_t j = lane; j < d; j += 64) p += X[i * d + j] * theta[j];
+            p = wave_sum(p);
+            const double r = (y[i] - p) * (y[i] - p);
+            if (lane == 0) {
+                losses[i] = r;
+                num += w[i] * r;
+                den += w[i];
+            }
         }
     }
     num = wave_sum(num);
@@ -132,16 +171,26 @@ __global__ __launch_bounds__(256) void linreg_scale_kernel(double *__restrict__ 
         losses[i] = 0.5 * losses[i] / sigma2;
 }
 
+template <bool MFMA>
 __global__ __launch_bounds__(256) void logistic_nll_kernel(const double *__restrict__ X,
                                                            const double *__restrict__ wv, double b,
                                                            int64_t n, int64_t d,
                                                            double *__restrict__ losses) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
-        double p = 0.0;
-        for (int64_t j = lane; j < d; j += 64) p += X[i * d + j] * wv[j];
-        p = wave_sum(p) + b;
-        if (lane == 0) losses[i] = p >= 0.0 ? log1p(exp(-p)) : -p + log1p(exp(p));
+    auto nll = [](double p) { return p >= 0.0 ? log1p(exp(-p)) : -p + log1p(exp(p)); };
+    if (MFMA) {
+        for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16; r0 < n; r0 += (int64_t)gridDim.x * 64) {
+            int myrow;
+            const double p = rows16_dot_mfma(X, wv, r0, n, d, myrow) + b;
+            if (myrow >= 0 && r0 + myrow < n) losses[r0 + myrow] = nll(p);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+            double p = 0.0;
+            for (int64_t j = lane; j < d; j += 64) p += X[i * d + j] * wv[j];
+            p = wave_sum(p) + b;
+            if (lane == 0) losses[i] = nll(p);
+        }
     }
 }
 
@@ -155,9 +204,12 @@ extern "C" int rlvi_linreg_losses_f64(const double *X, const double *y, const do
     hipStream_t st = static_cast<hipStream_t>(stream);
     // scratch region (NOT the M-step records, which must stay zero between epochs)
     double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
-    int nb = (int)((n + 3) / 4);
+    // X.theta on the fp64 matrix cores (16 rows per wave); RLVI_XW_MFMA=0: one wave dot product per row
+    const bool mfma = tune_get("RLVI_XW_MFMA", 1) != 0;
+    int nb = (int)(mfma ? (n + 63) / 64 : (n + 3) / 4);
     if (nb > 256) nb = 256;
-    int rc = launch(linreg_resid_kernel, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d, losses, part);
+    int rc = mfma ? launch(linreg_resid_kernel<true>, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d, losses, part)
+                  : launch(linreg_resid_kernel<false>, dim3(nb), dim3(256), 0, st, X, y, theta, w, n, d, losses, part);
     if (rc != 0) return rc;
     int nb2 = (int)((n + 255) / 256);
     if (nb2 > 256) nb2 = 256;
@@ -168,8 +220,10 @@ extern "C" int rlvi_logistic_nll_f64(const double *X, const double *w, double b,
                                      int64_t d, double *losses, void *stream) {
     if (!X || !w || !losses) return RLVI_E_NULL;
     if (n <= 0 || d <= 0) return RLVI_E_SHAPE;
-    int nb = (int)((n + 3) / 4);
+    const bool mfma = tune_get("RLVI_XW_MFMA", 1) != 0;
+    int nb = (int)(mfma ? (n + 63) / 64 : (n + 3) / 4);
     if (nb > 1024) nb = 1024;
-    return launch(logistic_nll_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), X, w, b,
-                  n, d, losses);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return mfma ? launch(logistic_nll_kernel<true>, dim3(nb), dim3(256), 0, st, X, w, b, n, d, losses)
+                : launch(logistic_nll_kernel<false>, dim3(nb), dim3(256), 0, st, X, w, b, n, d, losses);
 }

@@ -61,7 +61,8 @@ struct WsHeader {
     int32_t status;          // sticky RLVI_ST_* flags
     uint32_t pad0a;
     unsigned long long spin_ticks;   // bound of every inter-workgroup wait, 100 MHz ticks (0: default)
-    uint32_t pad0[60];
+    int32_t wls_minnorm;             // raised by the Cholesky kernel for the minimum-norm kernel behind it
+    uint32_t pad0[59];
     uint32_t mstep_ticket;   // last-block-done counter of the M-step kernel (self-resetting)
     uint32_t pad1[63];
     uint32_t epoch_base;     // tag base of the exchange slots (advanced by every coop kernel)

@@ -142,3 +142,16 @@ def _build_capi_example(tmp_path):
 def test_cpp_host_program_links_against_the_c_abi(lib, tmp_path):
     """examples/capi_smoke.cpp (no Python, no torch) compiles and links against the header + .so."""
     assert os.path.exists(_build_capi_example(tmp_path))
+
+
+def test_driver_models_and_schedule():
+    """ResNet18 / LeNet shapes and the LR factors of utils.get_lr_factor (CPU-only checks)."""
+    import torch
+    from rlvi_amd import driver
+    assert driver.get_lr_factor(0) == 1.0 and driver.get_lr_factor(20) == 1.0
+    assert driver.get_lr_factor(30) == pytest.approx(1.0 - 0.99 * 0.5)
+    assert driver.get_lr_factor(40) == pytest.approx(0.01) and driver.get_lr_factor(99) == 0.01
+    net = driver.ResNet18(3, 10)
+    assert net(torch.zeros(2, 3, 32, 32)).shape == (2, 10)
+    assert sum(p.numel() for p in net.parameters()) == 11173962 - 0   # CIFAR ResNet18, 10 classes
+    assert driver.LeNet(1, 10)(torch.zeros(2, 1, 28, 28)).shape == (2, 10)

@@ -625,16 +625,36 @@ def test_wls_solve_mfma_vs_lstsq(n, d, gpu):
     assert dev_status(ops, dev) == 0
 
 
-def test_wls_singular_sets_status(gpu):
+def test_wls_rank_deficient_gives_the_minimum_norm_solution(golden, gpu):
+    """A rank-deficient design: the reference's lstsq (rlvi.py:71,:80, LAPACK gelsd) returns the
+    minimum-norm least-squares solution -- so does the device path (RLVI_ST_SINGULAR is raised as
+    information, theta is pinv(X^T W X) X^T W y), for one weighted solve and for the whole estimator."""
     torch, ops, dev = gpu
-    X = np.ones((50, 3))                       # rank 1
-    y = np.arange(50.0)
+    from rlvi_amd import standard
     ws = ops.workspace(dev)
-    th = ops.wls_solve(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev), torch.ones(50, dtype=torch.float64, device=dev))
-    assert torch.isnan(th).all() and (ws.status() & 8)
-    from rlvi_amd import _lib
-    _lib.check(_lib.load().rlvi_workspace_init(ws.ptr, ws.nbytes, None), "init")
-    torch.cuda.synchronize()
+    X = np.ones((50, 3))                       # rank 1: theta = mean(y) / 3 on every column
+    y = np.arange(50.0)
+    th = ops.wls_solve(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev),
+                       torch.ones(50, dtype=torch.float64, device=dev))
+    np.testing.assert_allclose(th.cpu().numpy(), np.full(3, y.mean() / 3), rtol=1e-10)
+    assert ws.status() & 8
+    ws.clear_status()
+    g = golden("g5_standard")
+    X, y, w = g["linreg_rankdef/X"], g["linreg_rankdef/y"], g["linreg_rankdef/w"]
+    th = ops.wls_solve(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(w).to(dev))
+    np.testing.assert_allclose(th.cpu().numpy(), g["linreg_rankdef/theta_wls"], rtol=1e-8, atol=1e-10)
+    theta = standard.linear_regression(X, y)
+    np.testing.assert_allclose(theta, g["linreg_rankdef/theta"], rtol=1e-7, atol=1e-9)
+    assert ws.status() & 8
+    ws.clear_status()
+    # a full-rank solve afterwards lowers the hand-over flag again (no stale minimum-norm pass)
+    rng = np.random.default_rng(0)
+    Xf = rng.standard_normal((64, 5))
+    yf = rng.standard_normal(64)
+    th = ops.wls_solve(torch.from_numpy(Xf).to(dev), torch.from_numpy(yf).to(dev),
+                       torch.ones(64, dtype=torch.float64, device=dev))
+    np.testing.assert_allclose(th.cpu().numpy(), np.linalg.lstsq(Xf, yf, rcond=None)[0], rtol=1e-9, atol=1e-12)
+    assert ws.status() == 0
 
 
 def test_linreg_and_logistic_nll(gpu, oracle):
@@ -1058,4 +1078,98 @@ def test_top1_on_tied_maxima_golden(key, dtype, golden, gpu):
     zp[:, :z.shape[1]] = z
     o3, _ = ops.mstep_fwd_bwd(zp[:, :z.shape[1]], y, torch.arange(B, device=dev), w, r, want_grad=False)
     assert int(round(float(o3[3]))) == want_hits
+    assert ops.workspace(dev).status() == 0
+
+
+# ------------------------------------------------------------------------------ driver at cfg3 size
+def _eager_train_rlvi(train_loader, model, optimizer, residuals, weights, overfit, threshold):
+    """The statements of the reference's epoch (train_rlvi.py:52-106) with stock torch ops on the
+    device -- the checker for the driver's bookkeeping, not a product path."""
+    import torch
+    import torch.nn.functional as F
+    dev = weights.device
+    total, correct = 0, 0.0
+    for images, labels, indexes in train_loader:
+        images, labels, indexes = images.to(dev), labels.to(dev), indexes.to(dev)
+        logits = model(images)
+        pred = torch.max(F.softmax(logits.detach(), dim=1), 1)[1]
+        correct += 100.0 * float((pred == labels).sum()) / labels.shape[0]
+        total += 1
+        loss = F.cross_entropy(logits, labels, reduction='none')
+        residuals[indexes] = loss.detach()
+        loss = (loss * weights[indexes]).mean()
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+    with torch.no_grad():
+        residuals.sub_(residuals.min())
+        e = torch.exp(-residuals)
+        avg = 0.95
+        for _ in range(40):
+            ratio = avg / (1 - avg)
+            new = ratio * e / (1 + ratio * e)
+            err = torch.norm(new - weights)
+            weights[:] = new
+            avg = weights.mean()
+            if err < 1e-3:
+                break
+        weights.div_(weights.max())
+        if overfit:
+            beta = torch.sum(1 - weights) * 0.05
+            s, _ = torch.sort(weights, descending=True)
+            last = torch.sum(torch.cumsum(1 - s, 0) <= beta) - 1
+            threshold = max(threshold, s[last])
+            weights[weights < threshold] = 0
+    return correct / total, threshold
+
+
+def test_epoch_driver_cfg3_size_bookkeeping(gpu, tmp_path):
+    """BASELINE.json config 3 at its stated size (MNIST-shaped, batch 4096, N = 54 000) through the
+    driver: the overfit flag sequence, LR schedule, threshold, selection-mask counts, accuracies and the
+    TSV columns of the product path against the same driver run on a plain-torch restatement of the
+    epoch (same seed, same loader order).  The validation accuracy is scripted to drop at epoch 3 so
+    that the threshold / truncation path runs at N = 54 000 in both."""
+    torch, ops, dev = gpu
+    import torch.nn.functional as F
+    from rlvi_amd import driver
+
+    def scripted(base):
+        calls = {"n": 0}
+
+        def ev(loader, model, device):
+            calls["n"] += 1
+            acc = base(loader, model, device)
+            is_val = calls["n"] > 1 and calls["n"] % 2 == 0      # epoch 0: test; then val, test per epoch
+            epoch = calls["n"] // 2
+            return (acc if epoch < 3 else 0.3 * acc) if is_val else acc
+        return ev
+
+    @torch.no_grad()
+    def eager_eval(loader, model, device):
+        model.eval()
+        hit = tot = 0
+        for images, labels, _ in loader:
+            pred = torch.max(F.softmax(model(images.to(device)), dim=1), 1)[1]
+            hit += int((pred == labels.to(device)).sum())
+            tot += labels.numel()
+        return 100.0 * hit / tot
+
+    kw = dict(n_train=54000, n_val=6000, n_test=4096, batch_size=4096, n_epoch=6, noise_rate=0.5,
+              lr=0.05, seed=3, device="cuda:0", dataset="mnist")
+    log = tmp_path / "cfg3.tsv"
+    got = driver.run(log_path=str(log), evaluate_fn=scripted(driver.evaluate), **kw)
+    ref = driver.run(train_fn=_eager_train_rlvi, evaluate_fn=scripted(eager_eval), **kw)
+    assert len(got) == len(ref) == 6 and got[0]["epoch"] == 0
+    assert [r["fix"] for r in got] == [r["fix"] for r in ref] == [False, False, False, True, True, True]
+    assert [r["lr"] for r in got] == [r["lr"] for r in ref]
+    for a, b in zip(got, ref):
+        assert abs(a["tau"] - b["tau"]) <= 5e-3, (a, b)
+        assert abs(a["kept"] - b["kept"]) <= 0.005 * 54000, (a, b)
+        for k in ("train_acc", "val_acc", "test_acc", "clean", "corr"):
+            assert abs(a[k] - b[k]) <= 0.75, (k, a, b)
+    assert got[-1]["tau"] > 0 and got[-1]["kept"] < 54000          # truncation did run
+    lines = log.read_text().strip().splitlines()
+    assert lines[0] + "\n" == driver.LOG_HEADER and len(lines) == 1 + len(got)
+    assert lines[1].split("\t")[0] == "0:" and len(lines[1].split("\t")) == 9
+    assert all(len(l.split("\t")) == 9 for l in lines[1:])
     assert ops.workspace(dev).status() == 0
