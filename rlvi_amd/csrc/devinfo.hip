@@ -95,23 +95,25 @@ int g_ncaps = 0;
 int coop_cap_cached(const void *kernel, int block_threads, size_t dyn_lds) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    // debugging / tests (RLVI_COOP_CAP): pretend the device admits fewer co-resident workgroups
+    const int forced = tune_get("RLVI_COOP_CAP", 0);
+    int cap = -1;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         for (int i = 0; i < g_ncaps; ++i)
             if (g_caps[i].kernel == kernel && g_caps[i].dev == dev && g_caps[i].block == block_threads &&
                 g_caps[i].lds == dyn_lds)
-                return g_caps[i].cap;
+                cap = g_caps[i].cap;
     }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_lds) != hipSuccess)
-        per_cu = 0;
-    int cap = coop_blocks_from_occupancy(per_cu, block_threads, device_info().cus);
-    // debugging / tests: pretend the device admits fewer co-resident workgroups
-    const int forced = tune_get("RLVI_COOP_CAP", 0);
-    if (forced > 0 && forced < cap) cap = forced;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ncaps < MAX_CAPS && forced <= 0) g_caps[g_ncaps++] = CapEntry{kernel, dev, block_threads, dyn_lds, cap};
-    return cap;
+    if (cap < 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_lds) != hipSuccess)
+            per_cu = 0;
+        cap = coop_blocks_from_occupancy(per_cu, block_threads, device_info().cus);
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_ncaps < MAX_CAPS) g_caps[g_ncaps++] = CapEntry{kernel, dev, block_threads, dyn_lds, cap};
+    }
+    return (forced > 0 && forced < cap) ? forced : cap;
 }
 
 }  // namespace rlvi

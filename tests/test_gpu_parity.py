@@ -1173,3 +1173,40 @@ def test_epoch_driver_cfg3_size_bookkeeping(gpu, tmp_path):
     assert lines[1].split("\t")[0] == "0:" and len(lines[1].split("\t")) == 9
     assert all(len(l.split("\t")) == 9 for l in lines[1:])
     assert ops.workspace(dev).status() == 0
+
+
+# ------------------------------------------------------------------------------ co-residency
+def test_cooperating_grids_follow_the_occupancy_answer(gpu, oracle):
+    """Every kernel whose workgroups wait for each other sizes its grid from the occupancy query of
+    the device.  RLVI_COOP_CAP pretends the device admits only 100 (then 40) co-resident workgroups:
+    the E-step runs on 99 exchanging workgroups with longer slices (then on the iterative kernel),
+    the threshold on 64 (then on one) -- same results as on the full chip, status clean."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    L = _lib.load()
+    assert L.rlvi_device_cus() >= 1
+    N = 65536
+    r0 = synth.residual_vector("bimodal", N, 3)
+    ws = ops.Workspace(dev, N, N)
+    try:
+        for cap in (100, 40):
+            _lib.check(L.rlvi_tune_set(b"RLVI_COOP_CAP", cap), "tune")
+            res = torch.from_numpy(r0.copy()).to(dev)
+            w = torch.ones(N, device=dev)
+            iters = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.estep_deep(res, w, iters=iters, ws=ws)
+            ro, wo = r0.copy(), np.ones(N, np.float32)
+            it = oracle.update_sample_weights(ro, wo)
+            assert int(iters) == it
+            rel, small = rel_pi(w.cpu().numpy(), wo)
+            assert rel <= REL and small <= 1e-7
+            w_gpu = w.cpu().numpy().copy()
+            thr, mask, kept = ops.threshold_truncate(w, 0.0, want_mask=True, ws=ws)
+            thr_o = oracle.false_negative_criterion(w_gpu)
+            assert float(thr) == float(thr_o)
+            mask_o = oracle.truncate(w_gpu, thr_o)
+            assert np.array_equal(np.packbits(mask.cpu().numpy()), np.packbits(mask_o))
+            assert np.array_equal(w.cpu().numpy(), w_gpu) and int(kept) == int(mask_o.sum())
+            assert ws.status() == 0
+    finally:
+        _lib.check(L.rlvi_tune_set(b"RLVI_COOP_CAP", 0), "tune")
