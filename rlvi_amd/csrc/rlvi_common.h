@@ -98,15 +98,16 @@ constexpr size_t WS_XCHG3B_OFF = WS_XCHG3A_OFF + WS_XCHG3A_BYTES;
 constexpr int XCHG3B_REPLICAS = RLVI_XCHG3B_REPLICAS;     // the per-node totals are published in 8 copies (one per 32 pollers)
 constexpr size_t WS_XCHG3B_BYTES = 2ull * XCHG3B_REPLICAS * 64 * XCHG3_GRANULES * 8;   // 48 KiB
 // fourth exchange region (radix-descent threshold, threshold.hip): 32-byte records of four self-tagged
-// granules {count, min key, sum lo, sum hi} per (bin, workgroup): stage A [2 parities][256 bins][256
-// workgroups], stage B (the per-bin totals) [2][8 replicas][256 bins]
+// granules {count, min key, sum lo, sum hi}; a workgroup publishes up to 2 x 256 of them per exchange
+// (this digit's bins and, speculatively, the next digit's): stage A [2 parities][256 workgroups][512
+// records], stage B (the totals) [2][8 replicas][512 records]
 constexpr int THR_BINS = 256;
 constexpr int XCHG4_GRANULES = 4;
 constexpr int XCHG4B_REPLICAS = 8;
 constexpr size_t WS_XCHG4A_OFF = WS_XCHG3B_OFF + WS_XCHG3B_BYTES;
-constexpr size_t WS_XCHG4A_BYTES = 2ull * THR_BINS * MAX_COOP_WG * XCHG4_GRANULES * 8;        // 4 MiB
+constexpr size_t WS_XCHG4A_BYTES = 2ull * 2 * THR_BINS * MAX_COOP_WG * XCHG4_GRANULES * 8;    // 8 MiB
 constexpr size_t WS_XCHG4B_OFF = WS_XCHG4A_OFF + WS_XCHG4A_BYTES;
-constexpr size_t WS_XCHG4B_BYTES = 2ull * XCHG4B_REPLICAS * THR_BINS * XCHG4_GRANULES * 8;    // 128 KiB
+constexpr size_t WS_XCHG4B_BYTES = 2ull * XCHG4B_REPLICAS * 2 * THR_BINS * XCHG4_GRANULES * 8;    // 256 KiB
 // partial Gram matrices of the weighted-least-squares kernel: 8 workgroups x 64 x 64 doubles
 constexpr size_t WS_WLS_OFF = WS_XCHG4B_OFF + WS_XCHG4B_BYTES;
 constexpr int WLS_MAX_WG = 8;

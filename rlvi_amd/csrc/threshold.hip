@@ -209,6 +209,7 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
 // G == 1 needs no exchange at all.
 // ---------------------------------------------------------------------------------------
 constexpr int THQ_BLOCK = 256;
+constexpr unsigned long long THQ_ONE = 1ull << 40;      // one key in the packed {count, sum} LDS word
 constexpr int THQ_NW = THQ_BLOCK / WAVE;
 typedef unsigned int thq_vu4 __attribute__((ext_vector_type(4)));
 
@@ -222,15 +223,25 @@ struct ThqHist {                       // one histogram: what a workgroup publis
     uint32_t mn[THR_BINS];
 };
 
+// what a call leaves for the next one (behind the E-step's warm-start state in the workspace)
+struct ThrState {
+    long long n;                       // population of the last call
+    uint32_t key;                      // its v: the largest key whose inclusion did not fit
+    uint32_t valid;
+};
+constexpr size_t WS_THRSTATE_OFF = WS_TRAJ_OFF + 384;
+static_assert(384 + sizeof(ThrState) <= WS_TRAJ_BYTES, "threshold state must fit behind the trajectory state");
+
 struct ThqShared {
-    ThqHist h;                         // local histogram, then the totals
-    unsigned long long wsum[THQ_NW];   // cross-wave scratch of the scans / reductions
-    unsigned long long wcnt[THQ_NW];
-    uint32_t wmin[THQ_NW];
+    ThqHist h[2];                      // [0] this digit, [1] the next digit inside the guessed bin; then the totals
+    unsigned long long wsum[2 * THQ_NW];   // cross-wave scratch of the reductions
+    unsigned long long wcnt[2 * THQ_NW];
+    uint32_t wmin[2 * THQ_NW];
     uint32_t wtrue[THQ_NW];
-    unsigned long long r_sum, r_cnt;   // results of a pass
+    unsigned long long r_sum;          // results of a scan
     uint32_t r_min, r_b1;
     int dead;
+    unsigned long long stamps[60];     // RLVI_THR_DEBUG only
 };
 
 // 32-byte record = four granules {tag32 | payload32}: {count, min key, sum lo, sum hi}
@@ -261,9 +272,12 @@ __device__ __forceinline__ bool thq_load(gu64 *p, uint32_t tag, uint32_t &cnt, u
     return q0.y == tag && q0.w == tag && q1.y == tag && q1.w == tag;
 }
 
-// Totals of the per-workgroup histograms sh.h over the G workgroups, back into sh.h (identical
-// on every workgroup).  All threads call; returns false after a timeout (sh.dead set).
-#define THQ_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
+// Totals of the per-workgroup histograms sh.h[0 .. NH-1] over the G workgroups, back into sh.h
+// (identical on every workgroup).  All threads call; returns false after a timeout (sh.dead set).
+// Record r = half * 256 + bin lives at slot r of the stage-A row of its workgroup.
+// (stamps go to LDS and are copied out at the end: a global store in front of a barrier would cost its round trip)
+#define THQ_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) sh.stamps[dbgi++] = wall_clock64(); } while (0)
+template <int NH>
 __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bufB, uint32_t tag,
                                              int xstep, int G, WsHeader *hdr,
                                              unsigned long long spin_ticks, unsigned long long *dbg,
@@ -271,72 +285,119 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
     if (G == 1) return true;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int b = (int)blockIdx.x;
-    gu64 *A = bufA + (size_t)(xstep & 1) * THR_BINS * MAX_COOP_WG * XCHG4_GRANULES;
-    gu64 *B = bufB + (size_t)(xstep & 1) * XCHG4B_REPLICAS * THR_BINS * XCHG4_GRANULES;
-    // ---- stage A: thread t publishes this workgroup's record of bin t
-    // (layout [workgroup][bin]: the writer's 8 KiB are contiguous -- whole lines per store
+    constexpr int NREC = 2 * THR_BINS;                       // slots per workgroup row / totals row
+    gu64 *A = bufA + (size_t)(xstep & 1) * NREC * MAX_COOP_WG * XCHG4_GRANULES;
+    gu64 *B = bufB + (size_t)(xstep & 1) * XCHG4B_REPLICAS * NREC * XCHG4_GRANULES;
+    // ---- stage A: thread t publishes this workgroup's records of bin t
+    // (layout [workgroup][record]: the writer's bytes are contiguous -- whole lines per store
     //  instruction; the one-time scattered access is on the reducers' read side)
-    thq_store(A + ((size_t)b * THR_BINS + tid) * XCHG4_GRANULES, tag, sh.h.cnt[tid], sh.h.mn[tid],
-              sh.h.sum[tid]);
+    // every store instruction of the workgroup covers 4 KiB of its row without gaps: thread t writes
+    // the 16-byte half (c & 1) of record c >> 1, c = j * 256 + t, out of the LDS histogram
+#pragma unroll
+    for (int j = 0; j < 2 * NH; ++j) {
+        const int c = j * THQ_BLOCK + tid;
+        const int rec = c >> 1, hf = rec >> 8, bin = rec & (THR_BINS - 1);
+        thq_vu4 q;
+        if (c & 1) {
+            const unsigned long long sm = sh.h[hf].sum[bin];
+            q = (thq_vu4){(uint32_t)sm, tag, (uint32_t)(sm >> 32), tag};
+        } else {
+            q = (thq_vu4){sh.h[hf].cnt[bin], tag, sh.h[hf].mn[bin], tag};
+        }
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1"
+                     :
+                     : "v"((unsigned long long)(uintptr_t)(A + (size_t)b * NREC * XCHG4_GRANULES) + (unsigned long long)c * 16ull),
+                       "v"(q)
+                     : "memory");
+    }
     THQ_STAMP();   // stage A stored
     // ---- stage B: workgroup b adds the records of its 256 / G bins (G is 64, 128 or 256): G / 64
-    // waves per bin, lane = publishing workgroup, all bins of this workgroup gathered at once
+    // waves per bin, lane = publishing workgroup, all bins (and both halves) gathered at once
     {
         const int wpb = G >> 6;                              // waves per bin
         const int bin = b + G * (wave / wpb);                // this wave's bin
-        const int wg = (wave % wpb) * WAVE + lane;           // the workgroup whose record this lane reads
-        uint32_t c = 0, mn = 0xFFFFFFFFu;
-        unsigned long long sm = 0ull;
+        const int wg = (wave % wpb) * WAVE + lane;           // the workgroup whose records this lane reads
+        uint32_t c[NH], mn[NH];
+        unsigned long long sm[NH];
         bool timeout = false;
         {
-            gu64 *p = A + ((size_t)wg * THR_BINS + bin) * XCHG4_GRANULES;
             const unsigned long long t0 = wall_clock64();
+            bool got[NH];
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) got[hf] = false;
             for (unsigned spin = 0;; ++spin) {
-                if (thq_load(p, tag, c, mn, sm)) break;
-                if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
-            }
-        }
-        if (timeout) { c = 0; mn = 0xFFFFFFFFu; sm = 0ull; sh.dead = 1; }
-        THQ_STAMP();   // gathered
-        unsigned long long tc = wave_sum((unsigned long long)c);
-        unsigned long long ts = wave_sum(sm);
-        uint32_t tm = (uint32_t)wave_min((unsigned long long)mn);
-        if (wpb > 1) {
-            if (lane == 0) { sh.wcnt[wave] = tc; sh.wsum[wave] = ts; sh.wmin[wave] = tm; }
-            __syncthreads();
-            tc = 0ull; ts = 0ull; tm = 0xFFFFFFFFu;
-            const int w0 = wave / wpb * wpb;
-            for (int w = w0; w < w0 + wpb; ++w) {            // fixed order (integers: any order gives these bits)
-                tc += sh.wcnt[w]; ts += sh.wsum[w]; tm = sh.wmin[w] < tm ? sh.wmin[w] : tm;
-            }
-        }
-        // the first wave of a bin publishes its total: lane l stores granule l & 3 of replica l >> 2
-        if (wave % wpb == 0 && lane < XCHG4_GRANULES * XCHG4B_REPLICAS && sh.dead == 0) {
-            const int gq = lane & 3, rep = lane >> 2;
-            const uint32_t v = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
-                                                                       : (uint32_t)(ts >> 32);
-            __hip_atomic_store(B + ((size_t)rep * THR_BINS + bin) * XCHG4_GRANULES + gq,
-                               ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        THQ_STAMP();   // published
-    }
-    // ---- everybody: the 256 totals (thread t = bin t), replica blockIdx % 8
-    {
-        uint32_t c = 0, mn = 0xFFFFFFFFu;
-        unsigned long long sm = 0ull;
-        bool timeout = false;
-        __syncthreads();                                     // (sh.dead of this step, w* free again)
-        if (sh.dead == 0) {
-            gu64 *p = B + ((size_t)(b & (XCHG4B_REPLICAS - 1)) * THR_BINS + tid) * XCHG4_GRANULES;
-            const unsigned long long t0 = wall_clock64();
-            for (unsigned spin = 0;; ++spin) {
-                if (thq_load(p, tag, c, mn, sm)) break;
+                bool all = true;
+#pragma unroll
+                for (int hf = 0; hf < NH; ++hf) {
+                    if (!got[hf])
+                        got[hf] = thq_load(A + ((size_t)wg * NREC + hf * THR_BINS + bin) * XCHG4_GRANULES, tag,
+                                           c[hf], mn[hf], sm[hf]);
+                    all = all && got[hf];
+                }
+                if (all) break;
                 if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
             }
         }
         if (timeout) sh.dead = 1;
-        sh.h.cnt[tid] = c; sh.h.mn[tid] = mn; sh.h.sum[tid] = sm;
+        THQ_STAMP();   // gathered
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            if (timeout) { c[hf] = 0; mn[hf] = 0xFFFFFFFFu; sm[hf] = 0ull; }
+            const unsigned long long tc = wave_sum((unsigned long long)c[hf]);
+            const unsigned long long ts = wave_sum(sm[hf]);
+            const uint32_t tm = (uint32_t)wave_min((unsigned long long)mn[hf]);
+            if (lane == 0) { sh.wcnt[hf * THQ_NW + wave] = tc; sh.wsum[hf * THQ_NW + wave] = ts; sh.wmin[hf * THQ_NW + wave] = tm; }
+        }
+        __syncthreads();
+        // the first wave of a bin publishes its totals: lane l stores granule l & 3 of replica l >> 2
+        if (wave % wpb == 0 && lane < XCHG4_GRANULES * XCHG4B_REPLICAS && sh.dead == 0) {
+            const int gq = lane & 3, rep = lane >> 2;
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) {
+                unsigned long long tc = 0ull, ts = 0ull;
+                uint32_t tm = 0xFFFFFFFFu;
+                for (int w = wave; w < wave + wpb; ++w) {    // fixed order (integers: any order gives these bits)
+                    tc += sh.wcnt[hf * THQ_NW + w]; ts += sh.wsum[hf * THQ_NW + w];
+                    tm = sh.wmin[hf * THQ_NW + w] < tm ? sh.wmin[hf * THQ_NW + w] : tm;
+                }
+                const uint32_t v = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
+                                                                           : (uint32_t)(ts >> 32);
+                __hip_atomic_store(B + ((size_t)rep * NREC + hf * THR_BINS + bin) * XCHG4_GRANULES + gq,
+                                   ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        THQ_STAMP();   // published
+    }
+    // ---- everybody: the totals (thread t = bin t of every half), replica blockIdx % 8
+    {
+        __syncthreads();                                     // (sh.dead of this step, w* free again)
+        bool timeout = false;
+        uint32_t c[NH], mn[NH];
+        unsigned long long sm[NH];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) { c[hf] = 0; mn[hf] = 0xFFFFFFFFu; sm[hf] = 0ull; }
+        if (sh.dead == 0) {
+            const unsigned long long t0 = wall_clock64();
+            bool got[NH];
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) got[hf] = false;
+            for (unsigned spin = 0;; ++spin) {
+                bool all = true;
+#pragma unroll
+                for (int hf = 0; hf < NH; ++hf) {
+                    if (!got[hf])
+                        got[hf] = thq_load(B + ((size_t)(b & (XCHG4B_REPLICAS - 1)) * NREC + hf * THR_BINS + tid) *
+                                                   XCHG4_GRANULES, tag, c[hf], mn[hf], sm[hf]);
+                    all = all && got[hf];
+                }
+                if (all) break;
+                if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+            }
+        }
+        if (timeout) sh.dead = 1;
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) { sh.h[hf].cnt[tid] = c[hf]; sh.h[hf].mn[tid] = mn[hf]; sh.h[hf].sum[tid] = sm[hf]; }
     }
     __syncthreads();
     THQ_STAMP();   // totals in
@@ -351,7 +412,7 @@ template <int E, bool TRUNC>
 __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     float *__restrict__ w, int64_t N, float alpha, float *__restrict__ thr_io,
     uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out, int32_t *__restrict__ fallback,
-    void *ws, unsigned long long *__restrict__ dbg) {
+    void *ws, unsigned long long *__restrict__ dbg, int use_state) {
     __shared__ ThqShared sh;
     int dbgi = 0;
     THQ_STAMP();
@@ -361,13 +422,16 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
     gu64 *bufA = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG4A_OFF));
     gu64 *bufB = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG4B_OFF));
+    ThrState *state = reinterpret_cast<ThrState *>(wsb + WS_THRSTATE_OFF);
     uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const unsigned long long spin_ticks = spin_bound(hdr);
     int xstep = 0;
     if (tid == 0) sh.dead = 0;
-    // (read before the first exchange: workgroup 0 overwrites it after the last one)
+    // (read before the first exchange: workgroup 0 overwrites them after the last one)
     const float prev = TRUNC ? *thr_io : 0.0f;
+    const bool warm = use_state != 0 && state->valid != 0u && state->n == (long long)N;
+    const uint32_t guess = state->key;                   // the last call's v: its bytes are this call's guesses
 
     const int64_t L = (N + G - 1) / G;
     const int64_t lo_i = (int64_t)b * L < N ? (int64_t)b * L : N;
@@ -393,55 +457,41 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     auto pred = [&](unsigned long long s_int) {          // fl32(prefix sum) <= beta   (:46-47)
         return (float)((double)s_int * (1.0 / 16777216.0)) <= beta;
     };
-
-#pragma unroll 1
-    for (int level = 0; level < 4 && ok && !all_inside; ++level) {
-        const int shift = 24 - 8 * level;
-        // ---- local histogram of the keys inside the current prefix
-        sh.h.cnt[tid] = 0u; sh.h.mn[tid] = 0xFFFFFFFFu; sh.h.sum[tid] = 0ull;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool in = have[j] && (level == 0 || (k[j] >> (shift + 8)) == prefix);
-            if (in) {
-                const int bin = (int)((k[j] >> shift) & 0xFFu);
-                atomicAdd(&sh.h.cnt[bin], 1u);
-                atomicAdd(&sh.h.sum[bin], (unsigned long long)one_minus_u(__uint_as_float(k[j])));
-                atomicMin(&sh.h.mn[bin], k[j]);
-            }
-        }
-        if (level == 0 && nbad != 0u) atomicAdd(&sh.h.cnt[THR_BINS - 1], nbad);   // no valid key has top byte 0xFF
-        __syncthreads();
-        THQ_STAMP();   // histogram built
-        ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
-        ++tag; ++xstep;
-        if (!ok) {
-            if (level == 0 && b == 0 && tid == 0) *fallback = 0;
-            break;
-        }
-        if (level == 0) {
-            // out of [0, 1]: the generic kernel (enqueued behind this one) takes over
-            const bool range_bad = sh.h.cnt[THR_BINS - 1] != 0u;
-            if (b == 0 && tid == 0) *fallback = range_bad ? 1 : 0;
-            if (range_bad) { ok = false; break; }
-        }
-        // ---- wave 0: suffix sums T(t) = S_base + sum of bins >= t (lane l owns bins 4l..4l+3), the
-        // first bin b1 whose suffix fits (the predicate is monotone along the bins: T is non-increasing)
+    // One digit of the descent on the totals in sh.h[hf]: the first bin b1 whose suffix fits, then the
+    // sums / counts / smallest key of the bins >= b1 folded into the running state and the bin below
+    // b1 appended to the prefix.  Returns b1 (0: the whole range fits).
+    auto descend = [&](int hf, bool first, int digit_of_bin1) {
+        ThqHist &H = sh.h[hf];
+        // wave 0: suffix sums T(t) = S_base + sum of bins >= t (lane l owns bins 4l..4l+3); the
+        // predicate is monotone along the bins (T is non-increasing)
         if (wave == 0) {
             unsigned long long t4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t4[q] = sh.h.sum[4 * lane + q];
+            for (int q = 0; q < 4; ++q) t4[q] = H.sum[4 * lane + q];
             t4[2] += t4[3]; t4[1] += t4[2]; t4[0] += t4[1];
-            unsigned long long sfx = t4[0];                       // sum of my bins and, below, of all higher lanes'
-#pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                const unsigned long long os = __shfl_down(sfx, d, WAVE);
-                if (lane + d < WAVE) sfx += os;
+            // suffix sum over the 64 lanes without LDS: row_shl DPP steps inside the 16-lane rows
+            // (lanes past the row end read 0), then the totals of the higher rows through v_readlane
+            unsigned long long sfx = t4[0];
+            sfx += dpp_x<0x101>(sfx);
+            sfx += dpp_x<0x102>(sfx);
+            sfx += dpp_x<0x104>(sfx);
+            sfx += dpp_x<0x108>(sfx);
+            {
+                auto rl = [&](int src) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sfx, src);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sfx >> 32), src);
+                    return ((unsigned long long)hi << 32) | lo;
+                };
+                const unsigned long long r1 = rl(16), r2 = rl(32), r3 = rl(48);
+                const int row = lane >> 4;
+                sfx += row == 0 ? r1 + r2 + r3 : row == 1 ? r2 + r3 : row == 2 ? r3 : 0ull;
             }
             const unsigned long long higher = sfx - t4[0];        // bins of the lanes above mine
-            if (level == 0) {
+            if (first) {
                 // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44): the total is T(0)
-                const unsigned long long total = __shfl(sfx, 0, WAVE);
+                const unsigned long long total =
+                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sfx >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sfx);
                 beta = (float)((double)total * (1.0 / 16777216.0)) * alpha;
             }
             int ntrue = 0;
@@ -457,25 +507,13 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         }
         __syncthreads();
         const int b1 = (int)sh.r_b1;
-        if (level == 0) beta = __uint_as_float(sh.r_min);
-        if (b1 == 0) {
-            // every key of the range fits (only possible at level 0: a deeper range was entered
-            // because it does NOT fit as a whole): count = N, threshold = smallest weight
-            uint32_t m0 = (uint32_t)wave_min((unsigned long long)sh.h.mn[tid]);
-            if (lane == 0) sh.wmin[wave] = m0;
-            __syncthreads();
-            gmin = sh.wmin[0];
-#pragma unroll
-            for (int wv = 1; wv < THQ_NW; ++wv) gmin = sh.wmin[wv] < gmin ? sh.wmin[wv] : gmin;
-            all_inside = true;
-            break;
-        }
-        // count / smallest key of the bins >= b1 (masked block reductions), at level 0 the global minimum
+        if (first) beta = __uint_as_float(sh.r_min);
+        // count / smallest key of the bins >= b1 (masked block reductions), first: the global minimum
         {
             const bool up = tid >= b1;
-            const unsigned long long cw = wave_sum(up ? (unsigned long long)sh.h.cnt[tid] : 0ull);
-            const uint32_t mw = (uint32_t)wave_min(up ? (unsigned long long)sh.h.mn[tid] : 0xFFFFFFFFull);
-            const uint32_t gw = level == 0 ? (uint32_t)wave_min((unsigned long long)sh.h.mn[tid]) : 0u;
+            const unsigned long long cw = wave_sum(up ? (unsigned long long)H.cnt[tid] : 0ull);
+            const uint32_t mw = (uint32_t)wave_min(up ? (unsigned long long)H.mn[tid] : 0xFFFFFFFFull);
+            const uint32_t gw = first ? (uint32_t)wave_min((unsigned long long)H.mn[tid]) : 0u;
             if (lane == 0) { sh.wcnt[wave] = cw; sh.wmin[wave] = mw; sh.wtrue[wave] = gw; }
         }
         __syncthreads();
@@ -488,14 +526,125 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
                 mab = sh.wmin[wv] < mab ? sh.wmin[wv] : mab;
                 g0 = sh.wtrue[wv] < g0 ? sh.wtrue[wv] : g0;
             }
-            if (level == 0) gmin = g0;
-            S_base += sh.r_sum;
-            cnt_base += cab;
-            above = mab < above ? mab : above;
-            prefix = (prefix << 8) | (uint32_t)(b1 - 1);
-            below_cnt = sh.h.cnt[b1 - 1];
+            if (first) gmin = g0;
+            if (b1 > 0) {
+                S_base += sh.r_sum;
+                cnt_base += cab;
+                above = mab < above ? mab : above;
+                // (coarse first digit: bin 1 stands for the guessed top byte)
+                prefix = (prefix << 8) | (uint32_t)(digit_of_bin1 >= 0 ? digit_of_bin1 : b1 - 1);
+                below_cnt = H.cnt[b1 - 1];
+            }
         }
-        __syncthreads();                                  // r_*, w* and the histogram are rewritten by the next pass
+        __syncthreads();                                  // r_*, w* are rewritten by the next scan
+        return b1;
+    };
+
+    // Two digits per exchange when the last call's v is a usable guess: histogram [0] is this digit,
+    // [1] the NEXT digit of the keys inside the bin the guess names.  If the descent picks that very
+    // bin, its totals are already here and the next exchange is saved (a warm call: two exchanges for
+    // the four digits); if not, nothing is lost.
+    // A warm call does not histogram the first digit at all (every key takes part and half of them
+    // share a top byte: 64 lanes on one LDS word): three coarse bins {top byte below / equal to /
+    // above the guessed one}, accumulated in registers and reduced per wave, say whether the guess
+    // holds -- the scan must pick bin 1 -- and carry the total (beta), the global minimum and
+    // everything about the keys above.  A wrong guess costs that one exchange and restarts cold.
+    int level = 0;
+    bool use_warm = warm;
+#pragma unroll 1
+    while (level < 4 && ok && !all_inside) {
+        const int shift = 24 - 8 * level;
+        // (the guess applies while the prefix fixed so far agrees with its leading bytes)
+        const bool spec = use_warm && level < 3 && (level == 0 || (guess >> (shift + 8)) == prefix);
+        const bool coarse = spec && level == 0;
+        const uint32_t gbin = (guess >> shift) & 0xFFu;
+        // ---- local histograms of the keys inside the current prefix
+        sh.h[0].cnt[tid] = 0u; sh.h[0].mn[tid] = 0xFFFFFFFFu; sh.h[0].sum[tid] = 0ull;
+        if (spec) { sh.h[1].cnt[tid] = 0u; sh.h[1].mn[tid] = 0xFFFFFFFFu; sh.h[1].sum[tid] = 0ull; }
+        __syncthreads();
+        uint32_t cc[3] = {0u, 0u, 0u}, cm[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        unsigned long long cs[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool in = have[j] && (level == 0 || (k[j] >> (shift + 8)) == prefix);
+            if (in) {
+                const uint32_t bin = (k[j] >> shift) & 0xFFu;
+                const unsigned long long om = (unsigned long long)one_minus_u(__uint_as_float(k[j]));
+                if (coarse) {
+                    const int c3 = bin < gbin ? 0 : (bin == gbin ? 1 : 2);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (q == c3) { cc[q] += 1u; cs[q] += om; cm[q] = k[j] < cm[q] ? k[j] : cm[q]; }
+                } else {
+                    // (count and sum in ONE LDS atomic: count << 40 | sum; a workgroup holds at most
+                    //  8192 keys of at most 2^24 units each)
+                    atomicAdd(&sh.h[0].sum[bin], THQ_ONE | om);
+                    atomicMin(&sh.h[0].mn[bin], k[j]);
+                }
+                if (spec && bin == gbin) {
+                    const uint32_t bin2 = (k[j] >> (shift - 8)) & 0xFFu;
+                    atomicAdd(&sh.h[1].sum[bin2], THQ_ONE | om);
+                    atomicMin(&sh.h[1].mn[bin2], k[j]);
+                }
+            }
+        }
+        if (coarse) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned long long wc = wave_sum((unsigned long long)cc[q]);
+                const unsigned long long wsm = wave_sum(cs[q]);
+                const uint32_t wm = (uint32_t)wave_min((unsigned long long)cm[q]);
+                if (lane == 0) {
+                    atomicAdd(&sh.h[0].sum[q], (wc << 40) | wsm);
+                    atomicMin(&sh.h[0].mn[q], wm);
+                }
+            }
+        }
+        if (level == 0 && nbad != 0u) atomicAdd(&sh.h[0].sum[THR_BINS - 1], (unsigned long long)nbad << 40);   // no valid key has top byte 0xFF
+        __syncthreads();
+        {   // unpack count << 40 | sum
+            const unsigned long long p0 = sh.h[0].sum[tid];
+            sh.h[0].cnt[tid] = (uint32_t)(p0 >> 40);
+            sh.h[0].sum[tid] = p0 & (THQ_ONE - 1ull);
+            if (spec) {
+                const unsigned long long p1 = sh.h[1].sum[tid];
+                sh.h[1].cnt[tid] = (uint32_t)(p1 >> 40);
+                sh.h[1].sum[tid] = p1 & (THQ_ONE - 1ull);
+            }
+        }
+        __syncthreads();
+        THQ_STAMP();   // histograms built
+        ok = spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi)
+                  : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
+        ++tag; ++xstep;
+        if (!ok) {
+            if (level == 0 && b == 0 && tid == 0) *fallback = 0;
+            break;
+        }
+        if (level == 0) {
+            // out of [0, 1]: the generic kernel (enqueued behind this one) takes over
+            const bool range_bad = sh.h[0].cnt[THR_BINS - 1] != 0u;
+            if (b == 0 && tid == 0) *fallback = range_bad ? 1 : 0;
+            if (range_bad) { ok = false; break; }
+        }
+        const int b1 = descend(0, level == 0, coarse ? (int)gbin : -1);
+        if (b1 == 0) {
+            // every key of the range fits (only possible at level 0: a deeper range was entered
+            // because it does NOT fit as a whole): count = N, threshold = smallest weight
+            all_inside = true;
+            break;
+        }
+        if (coarse && b1 != 2) {
+            // the guessed top byte is not the one: start over without guesses
+            use_warm = false;
+            S_base = 0ull; cnt_base = 0ull; above = 0xFFFFFFFFu; prefix = 0u;
+            continue;
+        }
+        ++level;
+        if (spec && (coarse || (uint32_t)(b1 - 1) == gbin)) {
+            descend(1, false, -1);                       // (b1 >= 1 here: the bin as a whole does not fit)
+            ++level;
+        }
         THQ_STAMP();   // scan done
     }
 
@@ -535,21 +684,27 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
             }
         }
         if (kept_out != nullptr) {                            // uniform: one more exchange, bin 0 carries the count
-            sh.h.cnt[tid] = 0u; sh.h.mn[tid] = 0xFFFFFFFFu; sh.h.sum[tid] = 0ull;
+            sh.h[0].cnt[tid] = 0u; sh.h[0].mn[tid] = 0xFFFFFFFFu; sh.h[0].sum[tid] = 0ull;
             __syncthreads();
             const unsigned long long kw = wave_sum((unsigned long long)kept);
-            if (lane == 0) atomicAdd(&sh.h.sum[0], kw);
+            if (lane == 0) atomicAdd(&sh.h[0].sum[0], kw);
             __syncthreads();
-            ok = thq_exchange(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
+            ok = thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
             ++tag; ++xstep;
-            if (ok && b == 0 && tid == 0) *kept_out = (int64_t)sh.h.sum[0];
+            if (ok && b == 0 && tid == 0) *kept_out = (int64_t)sh.h[0].sum[0];
         }
     }
     THQ_STAMP();   // truncated
     if (b == 0 && tid == 0) {
         if (ok) *thr_io = thr;
-        // (the generic kernel behind this one looks at the flag: 1 only when the range check failed)
-        if (dbg != nullptr) dbg[63] = (unsigned long long)dbgi;
+        // this call's v for the next call's guesses (every workgroup read the old one before its first exchange)
+        state->n = (long long)N;
+        state->key = prefix;
+        state->valid = (ok && !all_inside) ? 1u : 0u;
+        if (dbg != nullptr) {
+            for (int q = 0; q < dbgi; ++q) dbg[q] = sh.stamps[q];
+            dbg[63] = (unsigned long long)dbgi;
+        }
         __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -578,6 +733,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
                                   : nullptr;
     int rc = RLVI_E_LIMIT;
     bool launched = false;
+    const int use_state = tune_get("RLVI_THR_WARM", 1);      // 0: never use the last call's key as a guess
 #define RLVI_THQ(E_, G_)                                                                         \
     do {                                                                                         \
         auto kern = threshold_radix_kernel<E_, TRUNC>;                                           \
@@ -585,7 +741,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
         if (!launched && (g_ == 1 || coop_cap(kern, THQ_BLOCK) >= g_) &&                           \
             (N + g_ - 1) / g_ <= (int64_t)(E_) * THQ_BLOCK) {                                      \
             rc = launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask,     \
-                        kept, flag, ws, dbg);                                                    \
+                        kept, flag, ws, dbg, use_state);                                         \
             if (rc == 0)                                                                         \
                 rc = launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, \
                             thr, mask, kept, (const int32_t *)flag);                             \
@@ -598,15 +754,26 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
     if (tune_get("RLVI_THR_RADIX", 1)) {
         const int force_g = tune_get("RLVI_THR_G", 0);
         if (N <= 1024 && !force_g) RLVI_THQ(4, 1);
+        // the histogram costs about 1 us per key slot of a thread (LDS atomics), an exchange grows with
+        // the number of publishing workgroups: 64 workgroups up to one key per thread, 128 up to four,
+        // then 256 (measured at N = 65 536: 26.3 / 25.5 / 29.8 us for 64 / 128 / 256)
         for (int G = 64; G <= 256; G *= 2) {
             if (force_g && G != force_g) continue;
             const int64_t L = (N + G - 1) / G;
+            const int emax = force_g ? 32 : (G == 64 ? 1 : G == 128 ? 4 : 32);
+            if (L > (int64_t)THQ_BLOCK * emax) continue;
             if (L <= THQ_BLOCK * 1) RLVI_THQ(1, G);
             else if (L <= THQ_BLOCK * 2) RLVI_THQ(2, G);
             else if (L <= THQ_BLOCK * 4) RLVI_THQ(4, G);
             else if (L <= THQ_BLOCK * 8) RLVI_THQ(8, G);
-            else if (G == 256 && L <= THQ_BLOCK * 16) RLVI_THQ(16, G);
-            else if (G == 256 && L <= THQ_BLOCK * 32) RLVI_THQ(32, G);
+            else if (L <= THQ_BLOCK * 16) RLVI_THQ(16, G);
+            else if (L <= THQ_BLOCK * 32) RLVI_THQ(32, G);
+        }
+        // (fewer co-resident workgroups than the preferred geometry asks for: any geometry that fits)
+        for (int G = 64; G <= 256 && !launched && !force_g; G *= 2) {
+            const int64_t L = (N + G - 1) / G;
+            if (L <= THQ_BLOCK * 8) RLVI_THQ(8, G);
+            else if (L <= THQ_BLOCK * 32) RLVI_THQ(32, G);
         }
         if (N <= 8192) RLVI_THQ(32, 1);          // (fewer than 64 co-resident workgroups: one workgroup)
     }

@@ -15,7 +15,7 @@ Host arrays cross PCIe once per call; use rlvi_amd.ops directly to keep data res
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 def _dev():
@@ -61,6 +61,9 @@ def linear_regression(X, y, maxiter=100, tol=1e-3, return_info=False):
         disc = torch.linalg.norm(theta - prev) / torch.linalg.norm(prev)
         if bool(disc <= tol):                               # rlvi.py:85-87 (one host sync)
             break
+    # a cooperating launch that could not run, a fixed point that did not converge: never silent
+    # (RLVI_ST_SINGULAR is information: the minimum-norm solution was returned, as lstsq does)
+    ops.workspace(dev).raise_on_status("linear_regression", mask=_lib.ST_TIMEOUT | _lib.ST_NOCONV)
     if return_info:
         return theta.cpu().numpy(), w.cpu().numpy(), outer
     return theta.cpu().numpy()

@@ -816,6 +816,9 @@ def test_select_smallest_vs_oracle(gpu, oracle):
         else:
             l = rng.random(n).astype(np.float32)
             l[rng.random(n) < 0.01] = np.nan
+            # NaN with the sign bit set (0xFFC00000: the x86 default, what inf - inf gives) orders last too
+            neg_nan = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
+            l[rng.random(n) < 0.01] = neg_nan
             l[rng.random(n) < 0.01] = np.inf
         for k in sorted({0, 1, n // 3, n - 1, n, n + 5} & set(range(0, n + 6))):
             got = ops.select_smallest(torch.from_numpy(l).to(dev), k).cpu().numpy()
