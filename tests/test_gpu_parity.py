@@ -1213,3 +1213,29 @@ def test_cooperating_grids_follow_the_occupancy_answer(gpu, oracle):
             assert ws.status() == 0
     finally:
         _lib.check(L.rlvi_tune_set(b"RLVI_COOP_CAP", 0), "tune")
+
+
+def test_threshold_guesses_from_the_previous_call(gpu, oracle):
+    """The radix descent takes two digits per exchange on the previous call's key.  A sequence of
+    vectors of one length through one workspace -- the same vector again (every guess right), a
+    slightly different one (top bytes right, low bytes wrong), a different distribution (top byte
+    wrong: restart) -- must give the oracle's threshold and mask every time."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(11)
+    N = 40000
+    ws = ops.Workspace(dev, N, N)
+    base = rng.random(N).astype(np.float32) ** 3
+    seqs = [base, base, (base * np.float32(0.999)).astype(np.float32), base,
+            rng.beta(0.3, 0.3, N).astype(np.float32), (rng.random(N) ** 0.1).astype(np.float32),
+            np.where(rng.random(N) < 0.7, 1.0, rng.random(N) * 1e-3).astype(np.float32), base]
+    for i, v in enumerate(seqs):
+        v = v.copy()
+        v[int(rng.integers(N))] = 1.0
+        w = torch.from_numpy(v.copy()).to(dev)
+        thr, mask, kept = ops.threshold_truncate(w, 0.0, want_mask=True, ws=ws)
+        thr_o = oracle.false_negative_criterion(v)
+        assert float(thr) == float(thr_o), (i, float(thr), float(thr_o))
+        mask_o = oracle.truncate(v, thr_o)
+        assert np.array_equal(mask.cpu().numpy(), mask_o) and int(kept) == int(mask_o.sum()), i
+        assert np.array_equal(w.cpu().numpy(), v), i
+    assert ws.status() == 0
