@@ -631,7 +631,9 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         int64_t cap = ((int64_t)wpc * cus + WPB - 1) / WPB;
         if (cap > MSTEP_MAX_BLOCKS) cap = MSTEP_MAX_BLOCKS;
         if (nb > cap) nb = cap;
-        const size_t lds = (size_t)WPB * SKB * 1024;
+        // (RLVI_MSTEP_LDS_PAD: extra LDS per workgroup = fewer resident workgroups per CU; with the grid
+        //  uncapped the dispatcher then hands the remaining tiles to whichever CU frees up first)
+        const size_t lds = (size_t)WPB * SKB * 1024 + (size_t)tune_get("RLVI_MSTEP_LDS_PAD", 0);
         if (kact == KMAX)
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, true>, dim3((unsigned)nb), dim3(WPB * WAVE),
                         lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
