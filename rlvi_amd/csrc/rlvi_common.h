@@ -86,17 +86,17 @@ constexpr size_t WS_PART_OFF = WS_TRAJ_OFF + WS_TRAJ_BYTES;
 constexpr int MSTEP_MAX_BLOCKS = 1024;   // partial records (and so workgroups) of one M-step launch
 constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
 constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
-// third exchange region (large-N trajectory E-step, estep_trajb.hip), 48-byte records of six
-// self-tagged fp32 granules {S, P, Q, D, min, -}: stage A [2 parities][64 nodes][256 workgroups], stage B [2][64 nodes]
-constexpr int XCHG3_GRANULES = 6;
+// third exchange region (trajectory E-step, estep_trajb.hip), 64-byte records of eight self-tagged
+// fp32 granules {S, P, Q, D, min, R3, R4, P2}: stage A [2 parities][64 nodes][256 workgroups], stage B [2][64 nodes]
+constexpr int XCHG3_GRANULES = 8;
 constexpr size_t WS_XCHG3A_OFF = WS_PART_OFF + WS_PART_BYTES;
-constexpr size_t WS_XCHG3A_BYTES = 2ull * 64 * MAX_COOP_WG * XCHG3_GRANULES * 8;   // 1.5 MiB
+constexpr size_t WS_XCHG3A_BYTES = 2ull * 64 * MAX_COOP_WG * XCHG3_GRANULES * 8;   // 2 MiB
 constexpr size_t WS_XCHG3B_OFF = WS_XCHG3A_OFF + WS_XCHG3A_BYTES;
 #ifndef RLVI_XCHG3B_REPLICAS
 #define RLVI_XCHG3B_REPLICAS 8
 #endif
 constexpr int XCHG3B_REPLICAS = RLVI_XCHG3B_REPLICAS;     // the per-node totals are published in 8 copies (one per 32 pollers)
-constexpr size_t WS_XCHG3B_BYTES = 2ull * XCHG3B_REPLICAS * 64 * XCHG3_GRANULES * 8;   // 48 KiB
+constexpr size_t WS_XCHG3B_BYTES = 2ull * XCHG3B_REPLICAS * 64 * XCHG3_GRANULES * 8;   // 64 KiB
 // fourth exchange region (radix-descent threshold, threshold.hip): 32-byte records of four self-tagged
 // granules {count, min key, sum lo, sum hi}; a workgroup publishes up to 2 x 256 of them per exchange
 // (this digit's bins and, speculatively, the next digit's): stage A [2 parities][256 workgroups][512

@@ -57,12 +57,16 @@ __device__ __forceinline__ void wave_sort_keys(float &key, int &src) {
 // HASQ: tQ is meaningful (second-order local model, quintic global model); otherwise first-order /
 // cubic.
 // ---------------------------------------------------------------------------------------
-template <bool FIRST, bool HASQ = true>
+// HI (first round of estep_trajb.hip): tR3 = sum e^3/(1+re)^4 and tR4 = sum e^4/(1+re)^5 (the third- and
+// fourth-order terms of S around the node) are given too; the chain then runs on the fourth-order
+// model and may ACCEPT THE ROUND WITHOUT A VERIFICATION ROUND (see below).
+template <bool FIRST, bool HASQ = true, bool HI = false>
 __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, double tP, double tQ,
                                          double tD,
                                          float gmin, bool dead, float rn_l, float shift, float invN,
                                          float tol, float *trace, bool want_nodes, int xstep,
-                                         unsigned long long *dbg) {
+                                         unsigned long long *dbg, double tR3 = 0.0, double tR4 = 0.0,
+                                         double tP2 = 0.0) {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool has = lane < Ke;
     float scale = 1.0f;
@@ -78,6 +82,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     bool finite = has ? (tS == tS && tP == tP && tD == tD && tQ == tQ && tS < 1e300 && tP < 1e300 &&
                              tD < 1e300 && tQ < 1e300)
                       : true;
+    if (HI && has) finite = finite && tR3 == tR3 && tR4 == tR4 && tP2 == tP2 && tR3 < 1e300 && tR4 < 1e300 && tP2 < 1e300;
     const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
     if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
         if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tQ); }
@@ -91,6 +96,9 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     const float iscale = FIRST ? __builtin_amdgcn_rcpf(scale) : 1.0f;
     const float b_l = has ? (float)tP * invN * iscale : 0.0f;
     const float c_l = has ? (float)tQ * invN * iscale * iscale : 0.0f;
+    // (mean-pi units, like b and c; P2 stays a plain sum: D = h^2 * P2)
+    const float r3_l = (HI && has) ? (float)tR3 * invN * iscale * iscale * iscale : 0.0f;
+    const float r4_l = (HI && has) ? (float)tR4 * invN * iscale * iscale * iscale * iscale : 0.0f;
     const float err_l = has ? sqrtf((float)tD) : __builtin_inff();                   // (:33)
     const unsigned long long stopmask = __ballot(has && err_l < tol);                // (:36)
     const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : Ke;
@@ -143,7 +151,16 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
             const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_l), step));
             if (lane == step) rnew_l = r;
             const float dr = r - rns;
-            const float avg = fmaf(dr, fmaf(-cc, dr, bb), a0);
+            float avg;
+            if (HI) {
+                // S(r' + d) = S + S' d - Q d^2 + R3 d^3 - R4 d^4 + ...  (alternating for d > 0, terms
+                // falling by a factor <= |d|/r')
+                const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r3_l), step));
+                const float r4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r4_l), step));
+                avg = fmaf(dr, fmaf(dr, fmaf(dr, fmaf(-r4, dr, r3), -cc), bb), a0);
+            } else {
+                avg = fmaf(dr, fmaf(-cc, dr, bb), a0);
+            }
             if (lane == step) avg_l = avg;
             r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
         }
@@ -228,6 +245,92 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     }
     float d_l = (has && lane < it_now) ? fabsf(rnew_l - rn) * __builtin_amdgcn_rcpf(rn) : 0.0f;
     float delta_w = group_allreduce<WAVE>(d_l, FMax());
+    // ---- Accept WITHOUT a verification round (HI, the local model held everywhere).
+    // What a verification round would deliver is the step errors err_k = ||pi(r_k) - pi(r_{k-1})||
+    // at the true nodes, i.e. the stop index.  This round measured D'_k at the GUESSED pair
+    // (r'_k, r'_{k-1}).  Write D = h^2 * P(rbar), h the step and rbar the midpoint of a pair: P is a
+    // smooth function of the pair's position (it is sum e^2/(1+re)^4 for small h/r and carries the
+    // curvature of pi otherwise), so
+    //     err_k = err'_k * |h_k / h'_k| * (rbar_k / rbar'_k)^(sigma/2),   sigma = dlnP/dlnrbar
+    // (a secant through the measured pairs) is good to second order in how far the pair moved.
+    // What it needs is h_k, i.e. the corrected nodes, whose relative error E_k is BOUNDED here: the
+    // model's remainder at node k is at most 1.34 R4 d^4 |d|/r' (alternating series with falling
+    // terms for d > 0, a geometric tail of ratio <= 1/4 for d < 0) plus the fp32 floor of the sums,
+    // it enters r_{k+1} through 1/(1-a)^2 and propagates with the chain's own factor s_k -- an
+    // affine scan over the lanes.  Every stop test up to the stop index has to clear tol by a band of
+    // 3 x sqrt2 E r/|h| + 2 x {2 mv^2 + |sigma dln rbar|/4 + 0.5 %}; anything inside a band: no
+    // accept, the verification round runs.
+    int it_acc = 0;
+    bool accept_now = false;
+    if (HI && FIRST && __all(inside) && !scanned && round_ok && trace == nullptr && steps >= 2) {
+        const bool live = has && lane < steps;
+        const float dk = rnew_l - rn;                                        // d at this node
+        const float om = 1.0f - avg_l;
+        const float iom2 = __builtin_amdgcn_rcpf(om * om);
+        const float rnext = __shfl_down(rnew_l, 1, WAVE);
+        const float irn = __builtin_amdgcn_rcpf(fmaxf(rnext, 1e-30f));
+        const float adk = fabsf(dk);
+        // remainder of mean(pi) at this node (+ the fp32 floor of the sums), as relative error of r_{k+1}
+        const float rem = 1.34f * r4_l * dk * dk * dk * dk * adk * __builtin_amdgcn_rcpf(rn) + 1e-7f * a0_l;
+        const bool act = live && lane + 1 < steps;
+        float of = act ? rem * iom2 * irn : 0.0f;                            // rho_k
+        float sc = act ? fminf(fabsf(b_l) * rnew_l * iom2 * irn, 1.0f) : 0.0f;   // s_k
+        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0)
+            dbg[828 + lane] = ((unsigned long long)__float_as_uint(sc) << 32) | __float_as_uint(of);
+#pragma unroll
+        for (int sh = 1; sh < WAVE; sh <<= 1) {                              // x -> sc x + of, inclusive scan
+            const float psc = __shfl_up(sc, sh, WAVE);
+            const float pof = __shfl_up(of, sh, WAVE);
+            if (lane >= sh) { of = fmaf(sc, pof, of); sc *= psc; }
+        }
+        float Ek = __shfl_up(of, 1, WAVE);                                   // bound on |r_k - true| / r_k
+        if (lane == 0) Ek = 0.0f;                                            // r_0 is exact
+        Ek += 1.2e-7f;                                                       // the nodes are fp32 numbers
+        const float Ekm = __shfl_up(Ek, 1, WAVE);
+        // the measured pairs: step, midpoint, P = D'/h'^2
+        const float rp_new = __shfl_up(rnew_l, 1, WAVE);
+        const float rp_old = __shfl_up(rn, 1, WAVE);
+        const float h = rnew_l - rp_new, hq = rn - rp_old;                   // corrected / guessed step
+        const float rbar = 0.5f * (rnew_l + rp_new), rbarq = 0.5f * (rn + rp_old);
+        const float lrq = __logf(fmaxf(rbarq, 1e-30f));
+        const float lpq = 2.0f * (__logf(fmaxf(err_l, 1e-30f)) - __logf(fmaxf(fabsf(hq), 1e-30f)));   // ln P'
+        const bool pair = live && lane >= 1;
+        // slope of ln P against ln rbar: secant to the previous pair where that is at least 2 % away,
+        // else (pairs crowding at a fixed point) the secant from the last pair to the nearest one that is
+        const float lrq_p = __shfl_up(lrq, 1, WAVE), lpq_p = __shfl_up(lpq, 1, WAVE);
+        const float lr_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lrq), steps - 1));
+        const float lp_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpq), steps - 1));
+        const unsigned long long far = __ballot(pair && fabsf(lrq - lr_last) >= 0.02f);
+        const int jstar = far ? 63 - (int)__builtin_clzll(far) : 1;
+        const float lr_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lrq), jstar));
+        const float lp_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpq), jstar));
+        const float slope_c = far ? (lp_j - lp_last) * __builtin_amdgcn_rcpf(lr_j - lr_last) : 0.0f;
+        const float slope_own = (lane >= 2 && fabsf(lrq - lrq_p) >= 0.02f) ? (lpq - lpq_p) * __builtin_amdgcn_rcpf(lrq - lrq_p)
+                                                                           : slope_c;
+        float slope = fminf(fmaxf(slope_own, -6.0f), 2.0f);
+        const float dl = __logf(fmaxf(rbar, 1e-30f)) - lrq;                  // how far the pair moved
+        const float ihq = __builtin_amdgcn_rcpf(fmaxf(fabsf(hq), 1e-30f));
+        const float err_hat = err_l * fabsf(h) * ihq * __expf(0.5f * slope * dl);
+        const float mvk = adk * __builtin_amdgcn_rcpf(rn);
+        const float mv = fmaxf(mvk, __shfl_up(mvk, 1, WAVE));                // relative move of the pair's nodes
+        const float node_term = 1.4143f * fmaxf(Ek, Ekm) * rbar * __builtin_amdgcn_rcpf(fmaxf(fabsf(h), 1e-30f));
+        float band = 3.0f * node_term + 2.0f * (2.0f * mv * mv + 0.25f * fabsf(slope * dl) + 0.005f);
+        float err_e = err_hat;
+        if (lane == 0) { err_e = err_l; band = 0.0f; }                       // node 0 and the caller's pi are exact
+        const bool clear = !live || (band < 0.5f && fabsf(err_e - tol) > band * err_e);
+        const unsigned long long stop_e = __ballot(live && err_e < tol);
+        const unsigned long long unclear = __ballot(!clear);
+        if (stop_e != 0ull) {
+            const int ks = (int)__builtin_ctzll(stop_e);                      // estimated stop index
+            const unsigned long long upto = ks >= 63 ? ~0ull : ((2ull << ks) - 1ull);
+            if ((unclear & upto) == 0ull && ks + 1 <= steps) { accept_now = true; it_acc = ks + 1; }
+        }
+        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+            dbg[700 + lane] = ((unsigned long long)__float_as_uint(err_e) << 32) | __float_as_uint(band);
+            dbg[764 + lane] = ((unsigned long long)__float_as_uint(Ek) << 32) | __float_as_uint(slope);
+            if (lane == 0) dbg[699] = ((unsigned long long)(accept_now ? 1 : 0) << 32) | (unsigned)it_acc;
+        }
+    }
     // Early accept: with nodes off by delta the corrected r are good to 0.25 delta^2, and the
     // errors (evaluated AT the nodes) to about delta*(r_k + r_{k-1})/|r_k - r_{k-1}| relative.
     // If every stop test up to `it` clears tol by 8x that margin, the stop index cannot change
@@ -261,10 +364,12 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         trace[2 * lane] = err_l;
         trace[2 * lane + 1] = avg_l;
     }
-    const float rfin_w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnew_l), it_now - 1));
+    const int it_out = accept_now ? it_acc : it_now;
+    if (accept_now) delta_w = 0.0f;
+    const float rfin_w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnew_l), it_out - 1));
     if (lane == 0) {
-        out.res_it = it_now;
-        out.res_found = (found && round_ok) ? 1 : 0;
+        out.res_it = it_out;
+        out.res_found = ((found || accept_now) && round_ok) ? 1 : 0;
         out.res_delta = delta_w;
         out.res_rfin = rfin_w;
         if (FIRST) out.res_min = gmin;

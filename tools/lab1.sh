@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/lab1
-timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/lab1/tests.log 2>&1
+timeout -k 10 900 python -m pytest tests -q -m gpu -k "estep or epoch or fused or cooperating or bench or train_rlvi or driver or warm or random" > gpurun_out/lab1/tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/lab1/tests.log
-tail -12 gpurun_out/lab1/tests.log
-timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -2
+tail -30 gpurun_out/lab1/tests.log
+timeout -k 10 200 python tools/dbg_estep.py 2>&1 | grep -v "amdgpu.ids" | tail -16

@@ -141,5 +141,18 @@ with torch.cuda.stream(side):
             print('  exchange', xs, '[stage1->, publish, polled, barrier, totals, chain, epilogue] us since kernel start:', [round(float(v - st[0]) / 100.0, 2) for v in rs])
         rd = raw[64:88]
         print('min, rfin:', np.array([raw[100] & 0xFFFFFFFF, raw[101] & 0xFFFFFFFF], np.uint32).view(np.float32))
+        full = ws.buf[off:off + 1000 * 8].cpu().numpy().view(np.uint64)
+        print("  wmin stored (wg0):", np.array([full[898] & 0xFFFFFFFF], np.uint32).view(np.float32), " totals val[4] lanes 0..3:", np.array(full[900:904] & 0xFFFFFFFF, np.uint32).view(np.float32), "nq", int(full[900] >> 32))
+        so = full[828:892]
+        print("  s_k    :", np.array(so >> 32, np.uint32).view(np.float32)[:24])
+        print("  rho_k  :", np.array(so & 0xFFFFFFFF, np.uint32).view(np.float32)[:24])
+        acc = full[699]
+        print("accept-without-verification:", int(acc >> 32), "it", int(acc & 0xFFFFFFFF))
+        eb = full[700:764]
+        print("  err_est:", np.array(eb >> 32, np.uint32).view(np.float32)[:24])
+        print("  band   :", np.array(eb & 0xFFFFFFFF, np.uint32).view(np.float32)[:24])
+        ee = full[764:828]
+        print("  E_k    :", np.array(ee >> 32, np.uint32).view(np.float32)[:24])
+        print("  slope  :", np.array(ee & 0xFFFFFFFF, np.uint32).view(np.float32)[:24])
         print("rounds (it, delta):", [(int(x >> 32), float(np.array([x & 0xFFFFFFFF], np.uint32).view(np.float32)[0])) for x in rd if x][:12])
     print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
