@@ -45,7 +45,7 @@ typedef unsigned int tb_vu4 __attribute__((ext_vector_type(4)));
 // size a slice is exactly one sample per thread (32.6 us per step against 33.9 with 240).
 constexpr int TB_G = RLVI_TB_G;      // exchanging workgroups at most (= exchange slots per node)
 constexpr int TB_CHUNK = 8;
-constexpr int TB_NV = 8;             // values of a record: {S, P, Q, D, min, R3, R4, P2}
+constexpr int TB_NV = 8;             // values of a record: {S, P, Q, D, min, R3, R4, -}
 constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
 
 template <int TB_NW>
@@ -81,11 +81,11 @@ __device__ __forceinline__ float wave_reduce8(const float (&v)[TB_CHUNK]) {
 // must carry `tag`.  Each 8-byte granule is self-tagged, so it does not matter that a 16-byte load
 // is only granule-atomic.
 __device__ __forceinline__ bool load_rec(gu64 *p, uint32_t tag, int nq, float (&val)[TB_NV]) {
-    // nq granules of the record carry this step's tag: 4 {S, P, Q, D}, 5 {.., min} or 8 {.., R3, R4, P2}
+    // nq granules of the record carry this step's tag: 4 {S, P, Q, D}, 5 {.., min} or 7 {.., R3, R4}
     tb_vu4 q0, q1, q2, q3;
     q2.x = 0u; q2.y = tag; q2.z = 0u; q2.w = tag;
     q3.x = 0u; q3.y = tag; q3.z = 0u; q3.w = tag;
-    if (nq > 5)
+    if (nq > 5) {
         asm volatile(
             "global_load_dwordx4 %0, %4, off sc1\n\t"
             "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
@@ -95,7 +95,8 @@ __device__ __forceinline__ bool load_rec(gu64 *p, uint32_t tag, int nq, float (&
             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
             : "v"((unsigned long long)(uintptr_t)p)
             : "memory");
-    else if (nq > 4) {
+        q3.w = tag;                      // (granule 7 is not part of a 7-granule record)
+    } else if (nq > 4) {
         asm volatile(
             "global_load_dwordx4 %0, %3, off sc1\n\t"
             "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
@@ -204,22 +205,22 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
 #pragma unroll
         for (int j = 0; j < E; ++j) fprev[j] = q0[j];      // "node -1" = the caller's pi (D_0)
         const int nchunks = (Ke + TB_CHUNK - 1) / TB_CHUNK;
-        // hi: the first round also takes R3 = sum e^3/(1+re)^4, R4 = sum e^4/(1+re)^5 (third- and
-        // fourth-order terms of S around the node) and P2 = sum e^2/(1+re)^4 (the step error of two
-        // close nodes is h * sqrt(P2)): what tj_chain needs to accept without a verification round
+        // HI: the first round also takes R3 = sum e^3/(1+re)^4 and R4 = sum e^4/(1+re)^5, the third- and
+        // fourth-order terms of S around the node: with them the corrected nodes are good enough (and
+        // provably so) for tj_chain to accept without a verification round
         auto sums = [&](auto hi_tag) {
             constexpr bool HI = decltype(hi_tag)::value;
 #pragma unroll 1
             for (int c = 0; c < nchunks; ++c) {
                 float aI[TB_CHUNK], aP[TB_CHUNK], aQ[TB_CHUNK], aD[TB_CHUNK];
-                float a3[TB_CHUNK], a4[TB_CHUNK], a2[TB_CHUNK];
+                float a3[TB_CHUNK], a4[TB_CHUNK];
 #pragma unroll
                 for (int q = 0; q < TB_CHUNK; ++q) {
                     const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn_l), c * TB_CHUNK + q));
                     // sample pairs in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
                     // samples per lane and instruction); only the reciprocal is per sample
                     f32x2_t pS = {0.0f, 0.0f}, pP = {0.0f, 0.0f}, pQ = {0.0f, 0.0f}, pD = {0.0f, 0.0f};
-                    f32x2_t p3 = {0.0f, 0.0f}, p4 = {0.0f, 0.0f}, p2 = {0.0f, 0.0f};
+                    f32x2_t p3 = {0.0f, 0.0f}, p4 = {0.0f, 0.0f};
                     const f32x2_t r2 = {r, r}, one2 = {1.0f, 1.0f};
 #pragma unroll
                     for (int j = 0; j + 1 < E; j += 2) {
@@ -236,14 +237,13 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                             const f32x2_t xyx = xy * x;
                             p3 += xyx;                                                   // e^3/(1+re)^4
                             p4 = __builtin_elementwise_fma(xyx, x, p4);                  // e^4/(1+re)^5
-                            p2 = __builtin_elementwise_fma(y, y, p2);                    // e^2/(1+re)^4
                         }
                         const f32x2_t d = f - (f32x2_t){fprev[j], fprev[j + 1]};          // pi_k - pi_{k-1}
                         pD = __builtin_elementwise_fma(d, d, pD);
                         fprev[j] = f.x; fprev[j + 1] = f.y;
                     }
                     float sI = pS.x + pS.y, sP = pP.x + pP.y, sQ = pQ.x + pQ.y, sD = pD.x + pD.y;
-                    float s3 = p3.x + p3.y, s4 = p4.x + p4.y, s2 = p2.x + p2.y;
+                    float s3 = p3.x + p3.y, s4 = p4.x + p4.y;
                     if constexpr ((E & 1) != 0) {
                         constexpr int j = E - 1;
                         const float t = r * ev[j];
@@ -258,25 +258,24 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                             const float xyx = xy * x;
                             s3 += xyx;
                             s4 = fmaf(xyx, x, s4);
-                            s2 = fmaf(y, y, s2);
                         }
                         const float d = f - fprev[j];
                         sD = fmaf(d, d, sD);
                         fprev[j] = f;
                     }
                     aI[q] = sI; aP[q] = sP; aQ[q] = sQ; aD[q] = sD;
-                    a3[q] = s3; a4[q] = s4; a2[q] = s2;
+                    a3[q] = s3; a4[q] = s4;
                 }
                 const float tI = wave_reduce8(aI);
                 const float tP = wave_reduce8(aP);
                 const float tQ = wave_reduce8(aQ);
                 const float tD = wave_reduce8(aD);
-                float t3 = 0.0f, t4 = 0.0f, t2 = 0.0f;
-                if (HI) { t3 = wave_reduce8(a3); t4 = wave_reduce8(a4); t2 = wave_reduce8(a2); }
+                float t3 = 0.0f, t4 = 0.0f;
+                if (HI) { t3 = wave_reduce8(a3); t4 = wave_reduce8(a4); }
                 if ((lane & 7) == 0) {
                     float *dst = sh.wp[wave][c * TB_CHUNK + (lane >> 3)];
                     *reinterpret_cast<float4 *>(dst) = make_float4(tI, tP, tQ, tD);
-                    if (HI) *reinterpret_cast<float4 *>(dst + 4) = make_float4(t3, t4, t2, 0.0f);
+                    if (HI) *reinterpret_cast<float2 *>(dst + 4) = make_float2(t3, t4);
                 }
             }
         };
@@ -295,7 +294,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         // (every replica on its own 3-KiB stretch: 256 pollers on one 768-byte stretch serialise at the
         //  memory side)
         gu64 *B = bufB + (size_t)(xstep & 1) * XCHG3B_REPLICAS * TJ_MAXK * XCHG3_GRANULES;
-        const int nq = hi_round ? 8 : (round == 0 ? 5 : 4);      // granules of a record that carry this step's tag
+        const int nq = hi_round ? 7 : (round == 0 ? 5 : 4);      // granules of a record that carry this step's tag
         // ---- stage A: this workgroup's record of every evaluated node
         // (waves 0..3 each combine the wave partials and store ONE granule per lane -- S, S', Q, D;
         //  a lane's write-through stores go out one after the other)
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
             gu64 *rec = A + ((size_t)lane * MAX_COOP_WG + b) * XCHG3_GRANULES;
             __hip_atomic_store(rec + wave, ((unsigned long long)tag << 32) | __float_as_uint((float)dq),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // second store of a lane: wave 3 the minimum (granule 4), waves 0..2 R3, R4, P2 (granules 5..7)
+            // second store of a lane: wave 3 the minimum (granule 4), waves 0 and 1 R3 and R4 (granules 5, 6)
             if (wave == 3 && nq > 4) {
                 float wmin = sh.pmin[0];
 #pragma unroll
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (dbg != nullptr && b == 0 && round == 0 && lane == 0) dbg[898] = __float_as_uint(wmin);
             }
-            if (wave < 3 && nq > 5) {
+            if (wave < 2 && nq > 5) {
                 float hq = 0.0f;
 #pragma unroll
                 for (int w = 0; w < TB_NW; ++w) hq += sh.wp[w][lane][4 + wave];
@@ -352,34 +351,33 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
                 const double vQ = (double)group_allreduce<WAVE>(mine ? val[2] : 0.0f, FAdd());
                 const double vD = (double)group_allreduce<WAVE>(mine ? val[3] : 0.0f, FAdd());
                 const float vM = group_allreduce<WAVE>((mine && nq > 4) ? val[4] : __builtin_inff(), FMin());
-                double v3 = 0.0, v4 = 0.0, v2 = 0.0;
+                double v3 = 0.0, v4 = 0.0;
                 if (nq > 5) {
                     v3 = (double)group_allreduce<WAVE>(mine ? val[5] : 0.0f, FAdd());
                     v4 = (double)group_allreduce<WAVE>(mine ? val[6] : 0.0f, FAdd());
-                    v2 = (double)group_allreduce<WAVE>(mine ? val[7] : 0.0f, FAdd());
                 }
                 if (lane == 0) {
                     sh.red[wave][0] = vS; sh.red[wave][1] = vP; sh.red[wave][2] = vQ;
                     sh.red[wave][3] = vD; sh.red[wave][4] = (double)vM;
-                    sh.red[wave][5] = v3; sh.red[wave][6] = v4; sh.red[wave][7] = v2;
+                    sh.red[wave][5] = v3; sh.red[wave][6] = v4;
                 }
             }
             __syncthreads();
             if (wave == 0 && !dead && sh.out.dead == 0) {
                 double tS = 0.0, tP = 0.0, tQ = 0.0, tD = 0.0, tM = (double)__builtin_inff();
-                double t3 = 0.0, t4 = 0.0, t2 = 0.0;
+                double t3 = 0.0, t4 = 0.0;
 #pragma unroll
                 for (int w = 0; w < TB_PER; ++w) {            // fixed order
                     tS += sh.red[w][0]; tP += sh.red[w][1]; tQ += sh.red[w][2]; tD += sh.red[w][3];
                     tM = sh.red[w][4] < tM ? sh.red[w][4] : tM;
-                    t3 += sh.red[w][5]; t4 += sh.red[w][6]; t2 += sh.red[w][7];
+                    t3 += sh.red[w][5]; t4 += sh.red[w][6];
                 }
                 // lane l stores granule l & 7 of replica l >> 3: one store per lane
                 static_assert(XCHG3B_REPLICAS * 8 == WAVE && TB_NV <= 8, "one granule of one replica per lane");
                 const int gq = lane & 7;
                 const float val = gq == 0 ? (float)tS : gq == 1 ? (float)tP : gq == 2 ? (float)tQ
                                   : gq == 3 ? (float)tD : gq == 4 ? (float)tM : gq == 5 ? (float)t3
-                                  : gq == 6 ? (float)t4 : (float)t2;
+                                  : (float)t4;
                 if (gq < nq)
                     __hip_atomic_store(B + ((size_t)(lane >> 3) * TJ_MAXK + b) * XCHG3_GRANULES + gq,
                                        ((unsigned long long)tag << 32) | __float_as_uint(val),
@@ -415,7 +413,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
             if (HI_OK && hi_round)
                 tj_chain<true, true, HI_OK>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2],
                                             (double)val[3], gm, dead, rn_l, shift, invN, tol, trace, true, xstep,
-                                            dbg, (double)val[5], (double)val[6], (double)val[7]);
+                                            dbg, (double)val[5], (double)val[6]);
             else if (round == 0)
                 tj_chain<true>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2], (double)val[3],
                                gm, dead,

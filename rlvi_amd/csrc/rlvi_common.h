@@ -87,7 +87,7 @@ constexpr int MSTEP_MAX_BLOCKS = 1024;   // partial records (and so workgroups) 
 constexpr int PART_STRIDE = 4;   // per block: {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits}
 constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
 // third exchange region (trajectory E-step, estep_trajb.hip), 64-byte records of eight self-tagged
-// fp32 granules {S, P, Q, D, min, R3, R4, P2}: stage A [2 parities][64 nodes][256 workgroups], stage B [2][64 nodes]
+// fp32 granules {S, P, Q, D, min, R3, R4, -}: stage A [2 parities][64 nodes][256 workgroups], stage B [2][64 nodes]
 constexpr int XCHG3_GRANULES = 8;
 constexpr size_t WS_XCHG3A_OFF = WS_PART_OFF + WS_PART_BYTES;
 constexpr size_t WS_XCHG3A_BYTES = 2ull * 64 * MAX_COOP_WG * XCHG3_GRANULES * 8;   // 2 MiB

@@ -65,8 +65,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
                                          double tD,
                                          float gmin, bool dead, float rn_l, float shift, float invN,
                                          float tol, float *trace, bool want_nodes, int xstep,
-                                         unsigned long long *dbg, double tR3 = 0.0, double tR4 = 0.0,
-                                         double tP2 = 0.0) {
+                                         unsigned long long *dbg, double tR3 = 0.0, double tR4 = 0.0) {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool has = lane < Ke;
     float scale = 1.0f;
@@ -82,7 +81,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     bool finite = has ? (tS == tS && tP == tP && tD == tD && tQ == tQ && tS < 1e300 && tP < 1e300 &&
                              tD < 1e300 && tQ < 1e300)
                       : true;
-    if (HI && has) finite = finite && tR3 == tR3 && tR4 == tR4 && tP2 == tP2 && tR3 < 1e300 && tR4 < 1e300 && tP2 < 1e300;
+    if (HI && has) finite = finite && tR3 == tR3 && tR4 == tR4 && tR3 < 1e300 && tR4 < 1e300;
     const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
     if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
         if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tQ); }

@@ -2,5 +2,6 @@
 mkdir -p gpurun_out/lab1
 timeout -k 10 900 python -m pytest tests -q -m gpu -k "estep or epoch or fused or cooperating or bench or train_rlvi or driver or warm or random" > gpurun_out/lab1/tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/lab1/tests.log
-tail -30 gpurun_out/lab1/tests.log
-timeout -k 10 200 python tools/dbg_estep.py 2>&1 | grep -v "amdgpu.ids" | tail -16
+tail -4 gpurun_out/lab1/tests.log
+timeout -k 10 200 python tools/time_parts.py --what step 2>&1 | grep -v "amdgpu.ids\|reps"
+timeout -k 10 200 python tools/time_parts.py --what estep 2>&1 | grep -v "amdgpu.ids\|reps"
