@@ -29,6 +29,41 @@ struct TjOut {
     float res_delta, res_rfin, res_min;
 };
 
+// Neighbour lanes and an affine scan over the 64 lanes without the LDS crossbar (a __shfl is a
+// ds_bpermute, ~100 cycles of latency each, and the recurrence is one long dependent chain).
+__device__ __forceinline__ float lane_up1(float v) {      // lane i <- lane i-1 (lane 0 <- 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));   // wave_shr:1
+}
+__device__ __forceinline__ float lane_down1(float v) {    // lane i <- lane i+1 (lane 63 <- 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));   // wave_shl:1
+}
+// Inclusive scan of the maps x -> sc x + of along the lanes (lane k ends with the composition of the
+// maps of lanes 0..k, applied in that order): row_shr steps inside the 16-lane rows, then the row ends
+// through v_readlane.
+__device__ __forceinline__ void affine_scan(float &sc, float &of) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int li = lane & 15;
+#define RLVI_AFF_STEP(CTRL, SH)                                                                  \
+    {                                                                                            \
+        const float psc = dpp_x<CTRL>(sc), pof = dpp_x<CTRL>(of);                                \
+        if (li >= (SH)) { of = fmaf(sc, pof, of); sc *= psc; }                                   \
+    }
+    RLVI_AFF_STEP(0x111, 1)
+    RLVI_AFF_STEP(0x112, 2)
+    RLVI_AFF_STEP(0x114, 4)
+    RLVI_AFF_STEP(0x118, 8)
+#undef RLVI_AFF_STEP
+    auto rl = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+    const float s1 = rl(sc, 15), o1 = rl(of, 15), s2 = rl(sc, 31), o2 = rl(of, 31), s3 = rl(sc, 47), o3 = rl(of, 47);
+    // prefixes of the rows: P1 = e1, P2 = e2 o e1, P3 = e3 o P2
+    const float p2s = s2 * s1, p2o = fmaf(s2, o1, o2);
+    const float p3s = s3 * p2s, p3o = fmaf(s3, p2o, o3);
+    const int row = lane >> 4;
+    const float ps = row == 1 ? s1 : row == 2 ? p2s : p3s;
+    const float po = row == 1 ? o1 : row == 2 ? p2o : p3o;
+    if (row > 0) { of = fmaf(sc, po, of); sc *= ps; }
+}
+
 // Ascending bitonic sort of one key per lane over the 64 lanes of a wave; `src` (initialised to the
 // lane id by the caller) ends up as the lane the key of each sorted position came from.  Ties are
 // ordered by `src`, so the compare-exchange is a strict total order and both lanes of a pair agree.
@@ -142,7 +177,9 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
     // that left it (cold or poor guesses) is redone on the global model below.
     if (!scanned) {
-#pragma unroll 1
+        // (unrolled by four: the per-node values of the next steps come through v_readlane ahead
+        //  of the dependent chain instead of inside it)
+#pragma unroll 4
         for (int step = 0; step < steps; ++step) {
             const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
             const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
@@ -156,7 +193,10 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
                 // falling by a factor <= |d|/r')
                 const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r3_l), step));
                 const float r4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r4_l), step));
-                avg = fmaf(dr, fmaf(dr, fmaf(dr, fmaf(-r4, dr, r3), -cc), bb), a0);
+                // (Estrin: three dependent levels behind dr instead of four)
+                const float dr2 = dr * dr;
+                const float lo2 = fmaf(dr, bb, a0), hi2 = fmaf(dr, r3, -cc);
+                avg = fmaf(dr2 * dr2, -r4, fmaf(dr2, hi2, lo2));
             } else {
                 avg = fmaf(dr, fmaf(-cc, dr, bb), a0);
             }
@@ -266,7 +306,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         const float dk = rnew_l - rn;                                        // d at this node
         const float om = 1.0f - avg_l;
         const float iom2 = __builtin_amdgcn_rcpf(om * om);
-        const float rnext = __shfl_down(rnew_l, 1, WAVE);
+        const float rnext = lane_down1(rnew_l);
         const float irn = __builtin_amdgcn_rcpf(fmaxf(rnext, 1e-30f));
         const float adk = fabsf(dk);
         // remainder of mean(pi) at this node (+ the fp32 floor of the sums), as relative error of r_{k+1}
@@ -276,19 +316,14 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         float sc = act ? fminf(fabsf(b_l) * rnew_l * iom2 * irn, 1.0f) : 0.0f;   // s_k
         if (dbg != nullptr && blockIdx.x == 0 && xstep == 0)
             dbg[828 + lane] = ((unsigned long long)__float_as_uint(sc) << 32) | __float_as_uint(of);
-#pragma unroll
-        for (int sh = 1; sh < WAVE; sh <<= 1) {                              // x -> sc x + of, inclusive scan
-            const float psc = __shfl_up(sc, sh, WAVE);
-            const float pof = __shfl_up(of, sh, WAVE);
-            if (lane >= sh) { of = fmaf(sc, pof, of); sc *= psc; }
-        }
-        float Ek = __shfl_up(of, 1, WAVE);                                   // bound on |r_k - true| / r_k
+        affine_scan(sc, of);                                                 // x -> sc x + of, inclusive
+        float Ek = lane_up1(of);                                             // bound on |r_k - true| / r_k
         if (lane == 0) Ek = 0.0f;                                            // r_0 is exact
         Ek += 1.2e-7f;                                                       // the nodes are fp32 numbers
-        const float Ekm = __shfl_up(Ek, 1, WAVE);
+        const float Ekm = lane_up1(Ek);
         // the measured pairs: step, midpoint, P = D'/h'^2
-        const float rp_new = __shfl_up(rnew_l, 1, WAVE);
-        const float rp_old = __shfl_up(rn, 1, WAVE);
+        const float rp_new = lane_up1(rnew_l);
+        const float rp_old = lane_up1(rn);
         const float h = rnew_l - rp_new, hq = rn - rp_old;                   // corrected / guessed step
         const float rbar = 0.5f * (rnew_l + rp_new), rbarq = 0.5f * (rn + rp_old);
         const float lrq = __logf(fmaxf(rbarq, 1e-30f));
@@ -296,7 +331,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         const bool pair = live && lane >= 1;
         // slope of ln P against ln rbar: secant to the previous pair where that is at least 2 % away,
         // else (pairs crowding at a fixed point) the secant from the last pair to the nearest one that is
-        const float lrq_p = __shfl_up(lrq, 1, WAVE), lpq_p = __shfl_up(lpq, 1, WAVE);
+        const float lrq_p = lane_up1(lrq), lpq_p = lane_up1(lpq);
         const float lr_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lrq), steps - 1));
         const float lp_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpq), steps - 1));
         const unsigned long long far = __ballot(pair && fabsf(lrq - lr_last) >= 0.02f);
@@ -311,7 +346,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         const float ihq = __builtin_amdgcn_rcpf(fmaxf(fabsf(hq), 1e-30f));
         const float err_hat = err_l * fabsf(h) * ihq * __expf(0.5f * slope * dl);
         const float mvk = adk * __builtin_amdgcn_rcpf(rn);
-        const float mv = fmaxf(mvk, __shfl_up(mvk, 1, WAVE));                // relative move of the pair's nodes
+        const float mv = fmaxf(mvk, lane_up1(mvk));                          // relative move of the pair's nodes
         const float node_term = 1.4143f * fmaxf(Ek, Ekm) * rbar * __builtin_amdgcn_rcpf(fmaxf(fabsf(h), 1e-30f));
         float band = 3.0f * node_term + 2.0f * (2.0f * mv * mv + 0.25f * fabsf(slope * dl) + 0.005f);
         float err_e = err_hat;
