@@ -177,9 +177,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
     // that left it (cold or poor guesses) is redone on the global model below.
     if (!scanned) {
-        // (unrolled by four: the per-node values of the next steps come through v_readlane ahead
-        //  of the dependent chain instead of inside it)
-#pragma unroll 4
+#pragma unroll 1
         for (int step = 0; step < steps; ++step) {
             const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
             const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
