@@ -60,15 +60,31 @@ extern "C" int rlvi_workspace_status(const void *ws, int32_t *status_host, void 
 
 // ---------------------------------------------------------------------------------------
 // In-batch E+M (online order): NLL pass -> E-step on this batch -> weighted loss + gradient.
-// Three launches of the kernels above; the second logits read is served by the Infinity Cache
-// for blocks up to ~100 MB.
+// One launch with the logit block resident in LDS between the passes where the shape allows
+// (fused_em.hip); otherwise the composition of the kernels above (the second logits read is then
+// served by the Infinity Cache for blocks up to ~100 MB).
 // ---------------------------------------------------------------------------------------
+namespace rlvi {
+int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, float *loss_rows, float *pi,
+                        int64_t B, int64_t C, float inv_scale, float tol, int maxiter, float *grad,
+                        int64_t ldg, float *out, int32_t *out_iters, void *ws, hipStream_t st, int *rc);
+}
 extern "C" int rlvi_fused_em_f32(const float *logits, int64_t ld, const int64_t *labels,
                                  float *loss_rows, float *pi, int64_t B, int64_t C,
                                  float inv_scale, float tol, int maxiter, float *grad_logits,
                                  int64_t ldg, float *out, int32_t *out_iters, void *ws,
                                  void *stream) {
     if (!loss_rows || !pi) return RLVI_E_NULL;
+    // one launch with the block resident in LDS when the shape allows it (fused_em.hip) ...
+    if (logits && labels && ws && B > 0 && C > 0 && !(((uintptr_t)labels & 7) || ((uintptr_t)pi & 3) ||
+        ((uintptr_t)loss_rows & 3) || ((uintptr_t)out & 3) || ((uintptr_t)ws & 255))) {
+        int frc = 0;
+        if (rlvi::try_launch_fused_em(logits, ld, labels, loss_rows, pi, B, C, inv_scale, tol, maxiter,
+                                      grad_logits, ldg, out, out_iters, ws,
+                                      static_cast<hipStream_t>(stream), &frc))
+            return frc;
+    }
+    // ... the composition otherwise
     // 1. l_i = CE(logits_i, y_i) -> loss_rows  (forward only; pi is not used for the scatter)
     int rc = rlvi_mstep_fwd_bwd_f32(logits, ld, labels, nullptr, pi, loss_rows, B, B, C, inv_scale,
                                     nullptr, 0, out, ws, stream);

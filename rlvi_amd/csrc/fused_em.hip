@@ -1,0 +1,391 @@
+// In-batch E+M in ONE launch (online-learning/main.py:296-299 order: losses of the batch -> E-step on
+// them -> the weighted gradient with the NEW pi; train_rlvi.py:14-38 for the E-step, :85-96 for the
+// loss and its gradient).  The whole logit block stays on the chip between the two passes:
+//
+//   1  every wave streams two 16-row tiles of the block into its own slice of LDS (nontemporal
+//      16-B/lane reads, as mstep.hip's wave-tile form), takes max / sum exp / NLL / top-1 per row and
+//      leaves exp(z - max) in place.  A workgroup of 8 waves holds 256 rows = 102 KiB of LDS at
+//      C = 100: one workgroup per CU, 256 workgroups hold 65 536 x 100 fp32 (26 MB of the chip's
+//      40 MB of LDS);
+//   2  the 256 NLLs of a workgroup ARE its slice of the E-step: waves 0..3 run the cooperating
+//      trajectory solve (rlvi_trajb.h) with one sample per thread, handed over through LDS -- no
+//      second read of anything from HBM, no kernel boundary;
+//   3  every wave turns its rows' NLLs into pi with the solve's (r, min), scales the resident tile
+//      (flat 16-B chunks: a chunk never straddles rows because 4 | C) and streams the gradient out
+//      with nontemporal stores; loss rows (l - min) and pi go out beside it; workgroup 0 gathers
+//      the 256 per-workgroup records into `out`.
+//
+// Same arithmetic, operation for operation, as the three-launch composition in aux.hip
+// (rlvi_mstep_fwd_bwd_f32 -> rlvi_estep_deep_f32 -> rlvi_mstep_fwd_bwd_f32): pi, the loss rows and
+// the gradient are bit-identical to it (tests/test_gpu_parity.py).  Eligibility: fp32, dense rows,
+// 4 | C, 32 <= C <= 128 (four lanes per row there too), 16 | B, 64 <= ceil(B/256) <= the co-resident workgroups of this device; everything
+// else takes the composition.
+#include "rlvi_trajb.h"
+
+namespace rlvi {
+
+typedef unsigned int fe_vu4 __attribute__((ext_vector_type(4)));
+
+constexpr int FE_WAVES = 8;                      // waves per workgroup
+constexpr int FE_THREADS = FE_WAVES * WAVE;
+constexpr int FE_TPW = 2;                        // tiles per wave
+constexpr int FE_R = 16;                         // rows per tile: four lanes per row
+constexpr int FE_ROWS = FE_WAVES * FE_TPW * FE_R;     // rows per workgroup = E-step slice
+constexpr int FE_EB = 256;                       // E-step threads (one sample each)
+static_assert(FE_ROWS == FE_EB, "a workgroup's rows are its E-step slice, one sample per thread");
+
+struct __attribute__((aligned(16))) FeRow { float inv_s, pw; int y; int pad; };
+
+// softmax entry -> gradient entry: e * inv_s, and for the label column -pi * inv_scale on top of the
+// ROUNDED product (mstep.hip's wave-tile form does that as a read-modify-write of the stored entry)
+__device__ __forceinline__ float fe_grad(float e, float inv_s, bool label, float pw, float inv_scale) {
+    float p;
+    {
+#pragma clang fp contract(off)
+        p = e * inv_s;
+    }
+    return label ? fmaf(-inv_scale, pw, p) : p;
+}
+
+template <int KMAX, bool EXACT>
+__global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
+    const float *__restrict__ logits, const int64_t *__restrict__ labels, float *__restrict__ loss_rows,
+    float *__restrict__ pi, int64_t B, int C, float inv_scale, float tol, int K,
+    float *__restrict__ grad, float *__restrict__ out, int32_t *__restrict__ out_iters, void *ws,
+    unsigned long long *__restrict__ dbg, int G) {
+    constexpr int V = 4, LG = 4;                                  // floats per lane vector, lanes per row
+    constexpr int NI = KMAX;                                      // 1-KiB pieces per tile (max)
+    constexpr int WTILE = NI * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [FE_WAVES][FE_TPW][WTILE]
+    __shared__ TbShared<FE_EB / WAVE> sh;
+    __shared__ float nll[FE_ROWS];
+    __shared__ FeRow rowinfo[FE_WAVES][FE_TPW][FE_R];
+    __shared__ double red[2 * FE_WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int g = lane & (LG - 1);
+    const int sub = lane / LG;
+    const int b = (int)blockIdx.x;
+    const int nv = C / V;                                         // vectors per row
+    const int nchunk = (FE_R * C * 4) >> 4;                       // 16-byte chunks of a tile
+    char *wbase = smem + (size_t)wave * FE_TPW * WTILE;
+    WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+
+    // RLVI_TJ_DEBUG: wall-clock stamps (100 MHz) of workgroup 0's phases, behind the solve's own
+#define FE_STAMP(k) do { if (dbg != nullptr && b == 0 && tid == 0) dbg[970 + (k)] = wall_clock64(); } while (0)
+    FE_STAMP(0);
+    const int64_t wg_row0 = (int64_t)b * FE_ROWS;
+    const int64_t wrow0 = wg_row0 + (int64_t)wave * FE_TPW * FE_R;
+
+    // ---- per-lane geometry (loop-invariant)
+    unsigned dma_off[NI];
+    int rowc[NI], colc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int c = i * WAVE + lane;
+        if (!(EXACT && i < NI - 1)) c = c < nchunk ? c : nchunk - 1;   // past the tile: its last chunk again
+        dma_off[i] = (unsigned)c * 16u;
+        rowc[i] = c / nv;
+        colc[i] = (c - rowc[i] * nv) * V;
+    }
+    int slot_off[KMAX];
+    bool live[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int vec = k * LG + g;
+        live[k] = (EXACT && k < KMAX - 1) || vec < nv;
+        slot_off[k] = (sub * C + (live[k] ? vec : nv - 1) * V) * 4;
+    }
+    const int row_off = sub * C * 4;
+
+    // ---- 1a  loads: the caller's pi (D_0 of the E-step) and the warm-start state first (loads return
+    // in order: behind the tiles they would hold tile 0 back until tile 1 has landed), labels, both tiles
+    const bool active = true;                     // two sampling groups of 256 threads (rlvi_trajb.h)
+    const int etid = tid & (FE_EB - 1);
+    const int64_t erow = wg_row0 + etid;
+    float q0[1];
+    q0[0] = erow < B ? pi[erow] : 0.0f;
+    const TbWarm wm = tb_warm(ws, B, K);
+    bool tile_ok[FE_TPW];
+    int64_t y64[FE_TPW];
+    fe_vu4 stg[FE_TPW][NI];
+#pragma unroll
+    for (int j = 0; j < FE_TPW; ++j) {
+        const int64_t r0 = wrow0 + (int64_t)j * FE_R;
+        tile_ok[j] = r0 < B;                                      // 16 | B: a tile is whole or absent
+        y64[j] = 0;
+        if (tile_ok[j]) {
+            y64[j] = labels[r0 + sub];
+            const char *src = reinterpret_cast<const char *>(logits + r0 * C);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                stg[j][i] = __builtin_nontemporal_load(reinterpret_cast<const fe_vu4 *>(src + dma_off[i]));
+        }
+    }
+    FE_STAMP(1);   // loads issued
+
+    // ---- 1b  per row: max, sum exp, NLL, top-1; exp(z - max) stays in the tile
+    float li[FE_TPW], ssum[FE_TPW];
+    int yl[FE_TPW];
+    bool okrow[FE_TPW];
+    float hits = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < FE_TPW; ++j) {
+        li[j] = __builtin_inff();
+        ssum[j] = 1.0f;
+        yl[j] = 0;
+        okrow[j] = false;
+        if (!tile_ok[j]) {
+            if (g == 0) nll[(wave * FE_TPW + j) * FE_R + sub] = __builtin_inff();
+            continue;
+        }
+        char *wtile = wbase + j * WTILE;
+        {
+            // (tile j only: loads return in order, so tile 0 is worked on while tile 1 is in flight)
+            fe_vu4 *t16 = reinterpret_cast<fe_vu4 *>(wtile);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) t16[i * WAVE + lane] = stg[j][i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        okrow[j] = true;
+        if (y64[j] < 0 || y64[j] >= C) { y64[j] = 0; okrow[j] = false; }
+        bad = bad || !okrow[j];
+        const int y = (int)y64[j];
+        yl[j] = y;
+        const float zy = *reinterpret_cast<const float *>(wtile + row_off + y * 4);
+        float v[KMAX][V];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            *reinterpret_cast<float4 *>(v[k]) = *reinterpret_cast<const float4 *>(wtile + slot_off[k]);
+        float m = v[0][0];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) m = __builtin_fmaxf(m, v[k][e]);
+        m = group_allreduce<LG>(m, [](float a, float c) { return __builtin_fmaxf(a, c); });
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float ex = mexp(v[k][e] - m);
+                v[k][e] = ex;
+                s += live[k] ? ex : 0.0f;
+            }
+        s = group_sum<LG>(s);
+        float l = __builtin_amdgcn_logf(s) * 0.69314718055994530942f - (zy - m);
+        bool hit = zy == m;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit && s >= 2.0f) != 0, 0)) {
+            // two exact maxima: the label counts only if it is the FIRST column at the maximum
+            // (torch.max order, deep-learning/utils.py:58); the tile still holds the logits here
+            int earlier = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const float4 z = *reinterpret_cast<const float4 *>(wtile + slot_off[k]);
+                const int col = (k * LG + g) * V;
+                const float zz[V] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                for (int e = 0; e < V; ++e) earlier += (live[k] && zz[e] == m && col + e < y) ? 1 : 0;
+            }
+            earlier = group_allreduce<LG>(earlier, FAdd());
+            hit = hit && earlier == 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            *reinterpret_cast<float4 *>(wtile + slot_off[k]) = *reinterpret_cast<const float4 *>(v[k]);
+        // a rejected row keeps the loss it had (the composition's forward pass skips it too)
+        if (!okrow[j]) l = loss_rows[wrow0 + j * FE_R + sub];
+        li[j] = l;
+        ssum[j] = s;
+        hits += (hit && okrow[j]) ? 1.0f : 0.0f;
+        if (g == 0) nll[(wave * FE_TPW + j) * FE_R + sub] = l;
+    }
+    if (bad) atomicOr(&hdr->status, RLVI_ST_RANGE);
+    FE_STAMP(2);   // rows done
+    __syncthreads();
+    FE_STAMP(3);
+
+    // ---- 2  E-step on the 256 NLLs of this workgroup (all waves take per-node sums, waves 0..3 the rest)
+    float l1[1], ev1[1];
+    l1[0] = erow < B ? nll[etid] : __builtin_inff();
+    const TbSolved sol = trajb_solve<1, FE_EB, FE_THREADS / FE_EB>(sh, wm, l1, q0, ev1, active, b, G, B, tol, K, out_iters,
+                                               nullptr, ws, dbg);
+    const float pmax = tb_pmax(sol);
+    FE_STAMP(4);   // solved
+
+    // ---- 3  pi, loss rows, the weighted gradient from the resident tile
+    float acc = 0.0f;
+    if (!sol.dead) {
+#pragma unroll
+        for (int j = 0; j < FE_TPW; ++j) {
+            if (!tile_ok[j]) continue;
+            const int64_t row = wrow0 + j * FE_R + sub;
+            const float lv = li[j] - sol.gmin;                      // residuals.sub_(min) (:27)
+            const float w = tb_weight(sol, pmax, expf(-lv));        // (:28, :30, :38)
+            const float pw = okrow[j] ? w : 0.0f;                   // a rejected row: zero gradient
+            const float gs = pw * inv_scale;
+            if (g == 0) {
+                loss_rows[row] = lv;
+                pi[row] = w;
+                FeRow ri;
+                ri.inv_s = gs * __builtin_amdgcn_rcpf(ssum[j]);
+                ri.pw = pw;
+                ri.y = yl[j];
+                ri.pad = 0;
+                rowinfo[wave][j][sub] = ri;
+            }
+            acc += okrow[j] ? li[j] * pw : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < FE_TPW; ++j) {
+            if (!tile_ok[j]) continue;
+            const fe_vu4 *t16 = reinterpret_cast<const fe_vu4 *>(wbase + j * WTILE);
+            char *gdst = reinterpret_cast<char *>(grad + (wrow0 + (int64_t)j * FE_R) * C);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const fe_vu4 raw = t16[dma_off[i] >> 4];
+                const FeRow ri = rowinfo[wave][j][rowc[i]];
+                const int d = ri.y - colc[i];
+                fe_vu4 o;
+                o.x = __float_as_uint(fe_grad(__uint_as_float(raw.x), ri.inv_s, d == 0, ri.pw, inv_scale));
+                o.y = __float_as_uint(fe_grad(__uint_as_float(raw.y), ri.inv_s, d == 1, ri.pw, inv_scale));
+                o.z = __float_as_uint(fe_grad(__uint_as_float(raw.z), ri.inv_s, d == 2, ri.pw, inv_scale));
+                o.w = __float_as_uint(fe_grad(__uint_as_float(raw.w), ri.inv_s, d == 3, ri.pw, inv_scale));
+                if ((EXACT && i < NI - 1) || i * WAVE + lane < nchunk)
+                    __builtin_nontemporal_store(o, reinterpret_cast<fe_vu4 *>(gdst + dma_off[i]));
+            }
+        }
+    }
+
+    FE_STAMP(5);   // gradient stores issued
+    // ---- the batch's four scalars: one self-tagged record per workgroup (sc1 stores, one granule per
+    // lane), workgroup 0 gathers the G records and adds them up in a fixed order.  (No release fence
+    // anywhere: a fence would wait for this CU's share of the gradient stores to drain.)
+    const double a = wave_sum((double)(g == 0 ? acc : 0.0f));
+    const double h = wave_sum((double)(g == 0 ? hits : 0.0f));
+    if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = h; }
+    __syncthreads();
+    const double inv_rows100 = 100.0 / (double)B;
+    double ta = 0.0, th = 0.0;
+#pragma unroll
+    for (int w = 0; w < FE_WAVES; ++w) { ta += red[2 * w]; th += red[2 * w + 1]; }
+    const double rec[PART_STRIDE] = {ta * (double)inv_scale, th * inv_rows100, ta, th};
+    if (out == nullptr) {
+        // accumulate for rlvi_epoch_end_f32, as rlvi_mstep_fwd_bwd_f32 without `out` does
+        if (tid == 0) {
+            double *p = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF) + (size_t)PART_STRIDE * b;
+#pragma unroll
+            for (int c = 0; c < PART_STRIDE; ++c) p[c] += rec[c];
+        }
+        return;
+    }
+    if (sol.dead) return;                 // (RLVI_ST_TIMEOUT is up: the host raises, `out` stays)
+    gu64 *frec = (gu64 *)(reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_FEREC_OFF));
+    const uint32_t ftag = sol.tag_free;
+    if (tid < 8) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(
+            (tid >> 1) == 0 ? rec[0] : (tid >> 1) == 1 ? rec[1] : (tid >> 1) == 2 ? rec[2] : rec[3]);
+        const uint32_t half = (tid & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        __hip_atomic_store(frec + (size_t)b * 8 + tid, ((unsigned long long)ftag << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    FE_STAMP(6);   // record stored
+    if (b != 0) return;
+    __shared__ double fin[FE_WAVES][PART_STRIDE];
+    __shared__ int fin_dead;
+    if (tid == 0) fin_dead = 0;
+    __syncthreads();
+    double t[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
+    if (wave < (G + WAVE - 1) / WAVE) {
+        const bool mine = tid < G;
+        const unsigned long long pa = (unsigned long long)(uintptr_t)(frec + (size_t)(mine ? tid : 0) * 8);
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long spin_ticks = spin_bound(hdr);
+        fe_vu4 r0, r1, r2, r3;
+        bool timeout = false;
+        for (unsigned spin = 0;; ++spin) {
+            asm volatile(
+                "global_load_dwordx4 %0, %4, off sc1\n\t"
+                "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                : "v"(pa)
+                : "memory");
+            const bool ok = !mine || (r0.y == ftag && r0.w == ftag && r1.y == ftag && r1.w == ftag &&
+                                      r2.y == ftag && r2.w == ftag && r3.y == ftag && r3.w == ftag);
+            if (__all(ok)) break;
+            if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+        }
+        if (timeout) {
+            if (lane == 0) { atomicOr(&hdr->status, RLVI_ST_TIMEOUT); fin_dead = 1; }
+        } else if (mine) {
+            t[0] = __longlong_as_double((long long)(((unsigned long long)r0.z << 32) | r0.x));
+            t[1] = __longlong_as_double((long long)(((unsigned long long)r1.z << 32) | r1.x));
+            t[2] = __longlong_as_double((long long)(((unsigned long long)r2.z << 32) | r2.x));
+            t[3] = __longlong_as_double((long long)(((unsigned long long)r3.z << 32) | r3.x));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PART_STRIDE; ++c) {
+        t[c] = wave_sum(t[c]);
+        if (lane == 0) fin[wave][c] = t[c];
+    }
+    __syncthreads();
+    if (tid == 0 && fin_dead == 0) {
+        double r[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < FE_WAVES; ++w)
+#pragma unroll
+            for (int c = 0; c < PART_STRIDE; ++c) r[c] += fin[w][c];
+        out[0] = (float)r[0]; out[1] = (float)r[1]; out[2] = (float)r[2]; out[3] = (float)r[3];
+    }
+    FE_STAMP(7);   // out written
+}
+
+// Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if the composition has to take it.
+int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, float *loss_rows, float *pi,
+                        int64_t B, int64_t C, float inv_scale, float tol, int maxiter, float *grad,
+                        int64_t ldg, float *out, int32_t *out_iters, void *ws, hipStream_t st, int *rc) {
+    if (tune_get("RLVI_FUSED_EM", 1) == 0) return 0;
+    if (grad == nullptr || ld != C || ldg != C || (C & 3) || C < 32 || C > 128 || (B & 15)) return 0;
+    if (((uintptr_t)logits & 15) || ((uintptr_t)grad & 15)) return 0;
+    if (maxiter < 1 || maxiter > TJ_MAXK) return 0;
+    const int64_t G64 = (B + FE_ROWS - 1) / FE_ROWS;
+    if (G64 < TJ_MAXK || G64 > TB_G) return 0;      // node k of the trajectory is reduced by workgroup k
+    const int G = (int)G64;
+    const int nv = (int)C / 4, k = (nv + 3) / 4;
+    const int debug = tune_get("RLVI_TJ_DEBUG", 0);
+    unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+    int launched = 0;
+#define RLVI_FE(K_, X_)                                                                              \
+    do {                                                                                             \
+        auto kern = fused_em_kernel<K_, X_>;                                                         \
+        const size_t lds = (size_t)FE_WAVES * FE_TPW * (K_) * 1024;                                  \
+        static bool attr_set = false;                                                                \
+        if (!attr_set) {                                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                (void)hipGetLastError();                                                             \
+                break;                                                                               \
+            }                                                                                        \
+            attr_set = true;                                                                         \
+        }                                                                                            \
+        if (coop_cap(kern, FE_THREADS, lds) < G) break;     /* all G workgroups must be resident */  \
+        *rc = launch(kern, dim3((unsigned)G), dim3(FE_THREADS), lds, st, logits, labels, loss_rows, pi, B, \
+                     (int)C, inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G);             \
+        launched = 1;                                                                                \
+    } while (0)
+    if (k <= 4) RLVI_FE(4, false);
+    else if (k == 7) RLVI_FE(7, true);
+    else RLVI_FE(8, false);
+#undef RLVI_FE
+    return launched;
+}
+
+}  // namespace rlvi

@@ -135,20 +135,6 @@ struct VecIO<uint16_t, 1> : VecIOBase<uint16_t, 1, VecIO<uint16_t, 1>> {
 constexpr int MSTEP_THREADS = 256;
 constexpr int MSTEP_WAVES = MSTEP_THREADS / WAVE;
 
-// exp(d) for d = z - max <= 0: one multiply by log2(e) and v_exp_f32.  d is an exact-to-1-ulp
-// fp32 difference, so the argument error is |d|*log2(e)*2^-24: below 1e-7 relative for every
-// term that is not already negligible against sum >= 1 (set RLVI_MSTEP_FAST_EXP=0 for ocml expf).
-#ifndef RLVI_MSTEP_FAST_EXP
-#define RLVI_MSTEP_FAST_EXP 1
-#endif
-__device__ __forceinline__ float mexp(float x) {
-#if RLVI_MSTEP_FAST_EXP
-    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
-#else
-    return expf(x);
-#endif
-}
-
 // Per-block partial record.  accum == 0: overwrite (a finalize launch follows); accum == 1: add
 // to what earlier mini-batches of this epoch left there (rlvi_epoch_end_f32 reduces and clears).
 // Every block owns its record, so there are no atomics and the sums are order-deterministic.
@@ -536,8 +522,10 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
                 // -onehot term: one read-modify-write of the label entry, ordered behind this wave's
                 // vector stores (LDS operations of a wave complete in order); the lanes of a group
                 // all write the same value
+                // (gs = pi * inv_scale unrounded inside the fma: spelled out so that fused_em.hip,
+                //  which promises the same bits, does not depend on what the compiler contracts)
                 float *zf = reinterpret_cast<float *>(zrow);
-                zf[y] = zf[y] - gs;
+                zf[y] = fmaf(-inv_scale, pi, zf[y]);
             }
         }
         if (g == 0 && okrow && residuals != nullptr) residuals[ix] = li;

@@ -112,7 +112,11 @@ constexpr size_t WS_XCHG4B_BYTES = 2ull * XCHG4B_REPLICAS * 2 * THR_BINS * XCHG4
 constexpr size_t WS_WLS_OFF = WS_XCHG4B_OFF + WS_XCHG4B_BYTES;
 constexpr int WLS_MAX_WG = 8;
 constexpr size_t WS_WLS_BYTES = (size_t)WLS_MAX_WG * 64 * 64 * 8;               // 256 KiB
-constexpr size_t WS_SCRATCH_OFF = WS_WLS_OFF + WS_WLS_BYTES;
+// per-workgroup result records of the one-launch in-batch E+M (fused_em.hip): 8 self-tagged granules
+// = the two halves of {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits} in fp64
+constexpr size_t WS_FEREC_OFF = WS_WLS_OFF + WS_WLS_BYTES;
+constexpr size_t WS_FEREC_BYTES = (size_t)MAX_COOP_WG * 8 * 8;                  // 16 KiB
+constexpr size_t WS_SCRATCH_OFF = WS_FEREC_OFF + WS_FEREC_BYTES;
 
 __host__ __device__ inline size_t ws_bytes_for(int64_t max_n, int64_t max_b) {
     // scratch: two fp32 vectors of max(max_n, max_b) (fused E+M keeps l and e there)
@@ -216,6 +220,20 @@ template <int G>
 __device__ __forceinline__ float group_sum(float v) { return group_allreduce<G>(v, FAdd()); }
 template <int G>
 __device__ __forceinline__ int group_min_i(int v) { return group_allreduce<G>(v, FMin()); }
+
+// exp(d) for d = z - max <= 0: one multiply by log2(e) and v_exp_f32.  d is an exact-to-1-ulp
+// fp32 difference, so the argument error is |d|*log2(e)*2^-24: below 1e-7 relative for every
+// term that is not already negligible against sum >= 1 (set RLVI_MSTEP_FAST_EXP=0 for ocml expf).
+#ifndef RLVI_MSTEP_FAST_EXP
+#define RLVI_MSTEP_FAST_EXP 1
+#endif
+__device__ __forceinline__ float mexp(float x) {
+#if RLVI_MSTEP_FAST_EXP
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#else
+    return expf(x);
+#endif
+}
 
 // Sums the per-block partial records in a fixed order and writes the four output scalars
 // (scaled by `scale`: 1 for a single batch, 1/batches for an epoch); optionally clears them.

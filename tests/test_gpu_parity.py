@@ -581,6 +581,93 @@ def test_fused_em_matches_composition(B, C, gpu, oracle):
     assert np.sqrt((diff ** 2).sum()) <= 2 * REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
 
 
+def _fused_em_run(ops, torch, dev, d, pi0, ws, fused, maxiter=40):
+    from rlvi_amd import _lib
+    L = _lib.load()
+    _lib.check(L.rlvi_tune_set(b"RLVI_FUSED_EM", 1 if fused else 0), "tune")
+    try:
+        pit = torch.from_numpy(pi0.copy()).to(dev)
+        rows = torch.full((pi0.shape[0],), 0.25, dtype=torch.float32, device=dev)
+        out, grad, rows, iters = ops.fused_em(torch.from_numpy(d["logits"]).to(dev),
+                                              torch.from_numpy(d["labels"]).to(dev), pit, ws=ws, rows=rows,
+                                              maxiter=maxiter)
+        torch.cuda.synchronize()
+        return (out.cpu().numpy(), grad.cpu().numpy(), rows.cpu().numpy(), pit.cpu().numpy(), int(iters))
+    finally:
+        _lib.check(L.rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
+
+
+@pytest.mark.parametrize("B,C", [(65536, 100), (16384, 100), (20000, 100), (65520, 100), (32768, 64),
+                                 (32768, 32), (30000, 128), (24576, 112), (40000, 104)])
+def test_fused_em_one_launch_equals_the_three_launch_composition(B, C, gpu, oracle):
+    """The one-launch in-batch E+M (fused_em.hip: the block stays in LDS between the NLL pass and the
+    gradient pass) against the composition of the M-step and E-step kernels on the same inputs: loss rows
+    bit for bit, pi and gradient bit for bit where the E-step slices coincide (to a few ulp elsewhere),
+    the four scalars to fp64 summation order; twice through one workspace
+    (the second call starts from the first one's trajectory).  Ties and a few labels out of range included."""
+    torch, ops, dev = gpu
+    # the same slices of the samples per cooperating workgroup in both forms: the same bits; otherwise the
+    # E-step's fp32 partial sums are grouped differently (256 workgroups there, ceil(B/256) here)
+    exact = (B + 255) // 256 == 256
+    d = synth.mstep_inputs(B, C, seed=B + 3 * C)
+    rng = np.random.default_rng(B + C)
+    for r in rng.integers(0, B, 40):                     # exact ties at the row maximum, label first / later
+        z = d["logits"][r]
+        j = int(np.argmax(z))
+        k = (j + 1 + int(rng.integers(C - 1))) % C
+        z[k] = z[j]
+        d["logits"][r] = z
+        d["labels"][r] = k if rng.random() < 0.5 else j
+    bad_rows = rng.integers(0, B, 3)
+    pi0 = rng.random(B).astype(np.float32)
+    for with_bad in (False, True):
+        if with_bad:
+            d["labels"][bad_rows] = [C, -1, C + 5]
+        ws_f, ws_c = ops.Workspace(dev, B, B), ops.Workspace(dev, B, B)
+        for call in range(2):
+            f = _fused_em_run(ops, torch, dev, d, pi0, ws_f, True)
+            c = _fused_em_run(ops, torch, dev, d, pi0, ws_c, False)
+            assert f[4] == c[4]
+            assert np.array_equal(f[2], c[2]), "loss rows"
+            if exact:
+                assert np.array_equal(f[3], c[3]), "pi"
+                assert np.array_equal(f[1], c[1]), "gradient"
+            else:
+                np.testing.assert_allclose(f[3], c[3], rtol=2e-6, atol=1e-30)
+                np.testing.assert_allclose(f[1], c[1], rtol=4e-6, atol=4e-6 / B)   # (softmax - onehot cancels)
+            np.testing.assert_allclose(f[0], c[0], rtol=2e-6)
+            assert f[0][3] == c[0][3]
+            st_f, st_c = ws_f.status(), ws_c.status()
+            assert st_f == st_c and (st_f != 0) == with_bad
+            ws_f.clear_status(); ws_c.clear_status()
+    # and against the oracle (clean labels)
+    d = synth.mstep_inputs(B, C, seed=B + C)
+    pi0 = np.ones(B, np.float32)
+    f = _fused_em_run(ops, torch, dev, d, pi0, ops.Workspace(dev, B, B), True)
+    loss, _ = oracle.nll_rows(d["logits"], d["labels"])
+    l2, w2 = loss.copy(), pi0.copy()
+    it = oracle.update_sample_weights(l2, w2)
+    assert f[4] == it
+    rel, small = rel_pi(f[3], w2)
+    assert rel <= REL and small <= 1e-7
+    np.testing.assert_allclose(f[2], l2, rtol=REL, atol=1e-6)
+
+
+def test_fused_em_maxiter_cap_and_shapes_that_take_the_composition(gpu, oracle):
+    torch, ops, dev = gpu
+    for (B, C, maxiter) in ((16384, 100, 3), (16384, 100, 64), (8192, 100, 40), (16392, 100, 40), (16384, 10, 40)):
+        d = synth.mstep_inputs(B, C, seed=5)
+        pi0 = np.ones(B, np.float32)
+        f = _fused_em_run(ops, torch, dev, d, pi0, ops.Workspace(dev, B, B), True, maxiter=maxiter)
+        c = _fused_em_run(ops, torch, dev, d, pi0, ops.Workspace(dev, B, B), False, maxiter=maxiter)
+        assert f[4] == c[4]
+        np.testing.assert_allclose(f[3], c[3], rtol=2e-6, atol=1e-30)
+        np.testing.assert_allclose(f[1], c[1], rtol=4e-6, atol=4e-6 / B)   # (softmax - onehot cancels)
+        loss, _ = oracle.nll_rows(d["logits"], d["labels"])
+        l2, w2 = loss.copy(), pi0.copy()
+        assert f[4] == oracle.update_sample_weights(l2, w2, maxiter=maxiter)
+
+
 # ------------------------------------------------------------------------------ fp64 paths
 def test_update_weights_f64_golden(golden, gpu):
     torch, ops, dev = gpu
