@@ -302,8 +302,16 @@ def main():
         def fused_only(i, ws):
             r = i % ROTATE
             ops.fused_em(logits[r], labels, pi_b, ws=ws, out=out, grad=grads[r], rows=rows_b, iters=it_f)
-        extra["fused_em_us"] = timed(fused_only, K, W, use_graph) / K * 1e3
+        fe_ms = timed(fused_only, K, W, use_graph) / K
+        extra["fused_em_us"] = fe_ms * 1e3
         extra["fused_em_iters"] = int(it_f.item())
+        # (one launch, the block resident in LDS between the passes, when the shape allows: fused_em.hip;
+        #  bytes = logits in + gradient out + labels, pi in/out, loss rows)
+        extra["fused_em_frac"] = (B * (2 * C * 4 + 8 + 12) / (fe_ms * 1e-3)) / HBM_PEAK
+        from rlvi_amd import _lib as _l
+        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
+        extra["fused_em_3launch_us"] = timed(fused_only, K, W, use_graph) / K * 1e3
+        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
         # the M-step at 4x the rows (3 rotating pairs = 630 MB): the same kernel with the fixed
         # launch / ramp-up share of a 10-us launch amortised -- separates steady-state bandwidth
         # from ramp-up by measurement

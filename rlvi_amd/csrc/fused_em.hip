@@ -81,14 +81,11 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
 
     // ---- per-lane geometry (loop-invariant)
     unsigned dma_off[NI];
-    int rowc[NI], colc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         int c = i * WAVE + lane;
         if (!(EXACT && i < NI - 1)) c = c < nchunk ? c : nchunk - 1;   // past the tile: its last chunk again
         dma_off[i] = (unsigned)c * 16u;
-        rowc[i] = c / nv;
-        colc[i] = (c - rowc[i] * nv) * V;
     }
     int slot_off[KMAX];
     bool live[KMAX];
@@ -125,6 +122,14 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
         }
     }
     FE_STAMP(1);   // loads issued
+    // (phase 3's chunk -> row / column map: integer divisions, behind the loads)
+    int rowc[NI], colc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = (int)(dma_off[i] >> 4);
+        rowc[i] = c / nv;
+        colc[i] = (c - rowc[i] * nv) * V;
+    }
 
     // ---- 1b  per row: max, sum exp, NLL, top-1; exp(z - max) stays in the tile
     float li[FE_TPW], ssum[FE_TPW];
