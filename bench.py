@@ -56,6 +56,12 @@ def parse():
                          "back to eager launches on every rank if any rank cannot).  Default off: the "
                          "eager loop costs ~37 us of host time per step, less than the GPU needs at "
                          "2+ ranks, and an eager RCCL call cannot hang a replay")
+    ap.add_argument("--estep-dist", default="auto", choices=["auto", "sharded", "replicated"],
+                    help="world > 1: 'sharded' = every rank keeps its own samples and the E-step kernel exchanges "
+                         "its per-node totals through the peers' inboxes (xGMI P2P, no collective call); "
+                         "'replicated' = RCCL all-gather of the residuals + the whole E-step on every rank; "
+                         "'auto' = sharded if its start-up self-check against the replicated result passes on "
+                         "every rank, else replicated")
     ap.add_argument("--force-collective", action="store_true",
                     help="debug: run the residual exchange (and its process group) at world size 1")
     ap.add_argument("--profile-only", action="store_true",
@@ -143,6 +149,14 @@ def main():
         r = i % ROTATE
         ops.mstep_fwd_bwd(logits[r], labels, idx_local, weights, residuals, inv_scale=inv_scale,
                           grad=grads[r], ws=ws, accumulate=True)
+        epoch_end_any(ws)
+
+    def epoch_end_any(ws):
+        if estep_mode[0] == "sharded":
+            # every rank keeps its own samples; the kernel's reducers exchange the per-node totals
+            ops.estep_sharded(residuals[lo_own:hi_own], weights[lo_own:hi_own], N, batches=1, out=out,
+                              iters=iters, ws=ws)
+            return
         if use_dist:
             rdist.exchange_residuals_owned(residuals, rank * B, (rank + 1) * B, force=a.force_collective)
         ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
@@ -153,7 +167,61 @@ def main():
                           grad=grads[r], ws=ws, accumulate=True)
 
     def estep_only(i, ws):
-        ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
+        if estep_mode[0] == "sharded":
+            epoch_end_any(ws)
+        else:
+            ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
+
+    estep_mode = ["replicated" if use_dist else "single"]
+    estep_note = ""
+    lo_own, hi_own = rank * B, (rank + 1) * B
+    peers_keep = []
+
+    def agree(flag, note=""):
+        """True only if `flag` holds on every rank (any backend)."""
+        if not (use_dist and dist.is_initialized()):
+            return bool(flag), note
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, (bool(flag), note))
+        bad = [f"rank {r}: {n}" for r, (f, n) in enumerate(got) if not f]
+        return len(bad) == 0, "; ".join(bad)
+
+    def choose_estep_mode(ws):
+        """Set up the peers' inboxes and check one sharded E-step against the replicated one on the same
+        vector (status clean, same iteration count, this rank's slice of pi to 1e-5): only then is the
+        sharded path used, on every rank or on none."""
+        from rlvi_amd import synth
+        note, ok = "", True
+        try:
+            peers_keep.append(rdist.setup_peers(ws))
+        except Exception as e:                               # noqa: BLE001 (Peers agreed on it: all ranks)
+            return "replicated", f"sharded unavailable ({e})"
+        try:
+            full = synth.residual_vector("bimodal", N, seed=5)
+            r_s = torch.from_numpy(full[lo_own:hi_own].copy()).to(dev)
+            w_s = torch.ones(B, dtype=torch.float32, device=dev)
+            it_s = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.estep_sharded(r_s, w_s, N, iters=it_s, ws=ws)
+            ws2 = ops.Workspace(dev, N, 0)
+            r_f = torch.from_numpy(full).to(dev)
+            w_f = torch.ones(N, dtype=torch.float32, device=dev)
+            it_f = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.estep_deep(r_f, w_f, iters=it_f, ws=ws2)
+            torch.cuda.synchronize()
+            st = ws.status()
+            ok = (st == 0 and int(it_s) == int(it_f) and torch.equal(r_s, r_f[lo_own:hi_own]) and
+                  torch.allclose(w_s, w_f[lo_own:hi_own], rtol=1e-5, atol=1e-30))
+            if not ok:
+                note = f"self-check failed (status {st}, iters {int(it_s)} vs {int(it_f)})"
+        except Exception as e:                               # noqa: BLE001
+            ok, note = False, f"self-check raised {type(e).__name__}: {e}"
+        ok, why = agree(ok, note)
+        if ok:
+            return "sharded", ""
+        ws.clear_status()
+        if a.estep_dist == "sharded" and rank == 0:
+            print(f"# --estep-dist sharded refused: {why}", file=sys.stderr)
+        return "replicated", why
 
     def sync_all():
         if use_dist:
@@ -166,6 +234,8 @@ def main():
     with torch.cuda.stream(side):
         ws = ops.Workspace(dev, N, B)
         torch.cuda.synchronize()
+        if use_dist and a.estep_dist != "replicated":
+            estep_mode[0], estep_note = choose_estep_mode(ws)
         step(0, ws)
         torch.cuda.synchronize()
         it_gpu = int(iters.item())
@@ -249,7 +319,8 @@ def main():
         return ms
 
     # world > 1: the RCCL all-gather is captured too when RCCL allows it (--dist-graph auto)
-    use_graph = (not a.no_graph) and (not use_dist or a.dist_graph == "auto")
+    # (the sharded step has no collective call in it: kernels only, captured like the one-GPU step)
+    use_graph = (not a.no_graph) and (not use_dist or a.dist_graph == "auto" or estep_mode[0] == "sharded")
     launch_mode = {}
     K, W = a.steps, a.warmup
     ms_total = timed(step, K, W, use_graph)
@@ -263,9 +334,14 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic logits {B}x{C} per GPU, N={N} samples, "
                                "M-step (lagged pi) + E-step every step, HBM-cold rotation of "
-                               f"{ROTATE} buffer pairs",
+                               f"{ROTATE} buffer pairs" +
+                               ("" if not use_dist else
+                                "; E-step sharded over the ranks (per-node totals through the peers' inboxes, "
+                                "no collective call)" if estep_mode[0] == "sharded" else
+                                "; residuals all-gathered, E-step replicated on every rank"),
                    "rows_per_gpu": B, "classes": C, "n_samples": N,
-                   "launch": launch_mode.get("step", "eager")},
+                   "launch": launch_mode.get("step", "eager"), "estep_dist": estep_mode[0],
+                   **({"estep_dist_note": estep_note} if estep_note else {})},
     }
     if a.profile_only:
         if rank == 0:
@@ -405,6 +481,9 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
+        dist.barrier()
+        for p in peers_keep:
+            p.close()
         dist.destroy_process_group()
 
 

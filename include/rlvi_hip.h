@@ -119,6 +119,37 @@ int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol, 
                         int32_t *out_iters, float *trace, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The same E-step with the samples SHARDED over the GPUs of one node (new; the reference is
+ * single-device): one process per GPU, this rank holds n_local of the n_all samples.  The
+ * per-sample work stays local; only the per-node totals of the trajectory solve (<= 24 nodes x 7
+ * fp32 per round) cross the GPUs, written by the kernel's reducer workgroups straight into the other
+ * ranks' inboxes over xGMI and summed in rank order, so every rank reaches the same fixed point bit
+ * for bit and writes pi / the min-shifted residuals of its own samples.  No collective-library call
+ * and no gather of the residual vector on the path.
+ *
+ *   rlvi_peer_alloc / _export / _open / _close / _free   one 64-KiB inbox per rank in uncached device
+ *       memory, exchanged as 64-byte IPC handles by the host program (rlvi_amd.dist.setup_peers)
+ *   rlvi_workspace_set_peers(ws, rank, world, inboxes, stream)   inboxes[r] = rank r's inbox as mapped
+ *       in this process; call at the same program point on every rank (resets the round counter)
+ *   rlvi_estep_sharded_f32   a collective: every rank calls it the same number of times; returns
+ *       RLVI_E_LIMIT when the shape is outside the trajectory kernel (n_local < 4096, ...).
+ *       out != NULL: this rank's M-step scalars of the epoch too (as rlvi_epoch_end_f32, x 1/batches).
+ *       Waits on a peer are bounded by 100 x the workspace's spin bound (a peer may legitimately be
+ *       late); a rank that gives up raises RLVI_ST_TIMEOUT.
+ * ------------------------------------------------------------------------------------- */
+#define RLVI_PEER_HANDLE_BYTES 64
+size_t rlvi_peer_inbox_bytes(void);
+int rlvi_peer_alloc(void **inbox);
+int rlvi_peer_free(void *inbox);
+int rlvi_peer_export(void *inbox, void *handle64);
+int rlvi_peer_open(const void *handle64, void **inbox);
+int rlvi_peer_close(void *inbox);
+int rlvi_workspace_set_peers(void *ws, int rank, int world, void *const *inboxes, void *stream);
+int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t n_local, int64_t n_all,
+                           float tol, int maxiter, int64_t batches, float *out, int32_t *out_iters,
+                           void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * End of an epoch in one call, replaces train_rlvi.py:99-105: update_sample_weights over all N
  * samples; if `overfit`, *thr_inout = max(*thr_inout, criterion) and the truncation; and, if
  * out != NULL, the epoch's M-step scalars reduced from the accumulate-mode records by an extra

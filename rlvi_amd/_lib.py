@@ -26,6 +26,14 @@ SIGNATURES = {
     "rlvi_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
     "rlvi_workspace_status": (_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "rlvi_workspace_clear_status": (_int, [_vp, _vp]),
+    "rlvi_peer_inbox_bytes": (ctypes.c_size_t, []),
+    "rlvi_peer_alloc": (_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "rlvi_peer_free": (_int, [_vp]),
+    "rlvi_peer_export": (_int, [_vp, ctypes.c_char_p]),
+    "rlvi_peer_open": (_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "rlvi_peer_close": (_int, [_vp]),
+    "rlvi_workspace_set_peers": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_void_p), _vp]),
+    "rlvi_estep_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _f32, _int, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_mstep_fwd_bwd_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                       _vp, _i64, _vp, _vp, _vp]),
     "rlvi_mstep_fwd_bwd_bf16": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,

@@ -21,7 +21,8 @@ enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
 // estep_trajb.hip: the trajectory solver of the deep variant (returns 0 when not applicable)
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
-                           float *mstep_out, double mstep_scale, int *rc);
+                           float *mstep_out, double mstep_scale, int *rc, int64_t n_all = 0,
+                           int sharded = 0);
 
 // t/(1+t) etc.: fp32 uses v_rcp_f32 (1 ulp) + multiply instead of the ~15-instruction IEEE
 // division sequence: <= 2 ulp on pi, two orders of magnitude inside the 1e-5 parity budget, and
@@ -232,6 +233,29 @@ extern "C" int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, 
         return RLVI_E_ALIGN;
     return launch_estep<float, VAR_DEEP>(residuals, weights, N, tol, maxiter, out_iters, trace, ws,
                                          static_cast<hipStream_t>(stream));
+}
+
+// The E-step with the samples sharded over the ranks of one node (one process per GPU): this rank's
+// n_local residuals / weights, n_all samples over all ranks.  Only the per-node totals of the trajectory
+// solve cross the GPUs (a few hundred bytes per rank and round, written by the kernel itself into the
+// peers' inboxes: rlvi_workspace_set_peers); every rank ends with the same fixed point and its own
+// slice of pi.  RLVI_E_LIMIT if the trajectory kernel does not take this shape (then gather the
+// residuals and run rlvi_estep_deep_f32 on the whole vector).
+// out != NULL: also this rank's M-step scalars of the epoch, as rlvi_epoch_end_f32 reduces them
+// (scaled by 1/batches) -- the epoch end of a rank in one launch.
+extern "C" int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t n_local, int64_t n_all,
+                                      float tol, int maxiter, int64_t batches, float *out,
+                                      int32_t *out_iters, void *ws, void *stream) {
+    if (!residuals || !weights || !ws) return RLVI_E_NULL;
+    if (n_local <= 0 || n_all < n_local || maxiter < 0 || batches < 0) return RLVI_E_SHAPE;
+    if (((uintptr_t)residuals & 3) || ((uintptr_t)weights & 3) || ((uintptr_t)out & 3) || ((uintptr_t)ws & 255))
+        return RLVI_E_ALIGN;
+    int rc = 0;
+    if (try_launch_estep_trajb(residuals, weights, n_local, tol, maxiter, out_iters, nullptr, ws,
+                               static_cast<hipStream_t>(stream), out, batches > 0 ? 1.0 / (double)batches : 1.0,
+                               &rc, n_all, 1))
+        return rc;
+    return RLVI_E_LIMIT;
 }
 
 extern "C" int rlvi_update_weights_f64(const double *losses, int64_t n, double tol, int maxiter,

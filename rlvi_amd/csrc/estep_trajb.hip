@@ -33,7 +33,8 @@ template <int E, int TB_BLOCK>
 __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
-    float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G) {
+    float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G,
+    int64_t Nall, PeerTable *__restrict__ pt) {
     // G <= TB_G exchanging workgroups (what is provably co-resident on this device), block G = the
     // epoch-end reduction
     if ((int)blockIdx.x == G) {   // epoch end: reduce + clear the M-step records (own CU)
@@ -47,7 +48,9 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     const int64_t L = (N + G - 1) / G;
     const int64_t lo = (int64_t)b * L < N ? (int64_t)b * L : N;
     const int64_t hi = lo + L < N ? lo + L : N;
-    const TbWarm wm = tb_warm(ws, N, K);
+    // (sharded over several GPUs: N samples here, Nall over all ranks, pt the peers' inboxes;
+    //  otherwise Nall == N and pt == nullptr)
+    const TbWarm wm = tb_warm(ws, Nall, K);
 
     // ---- slice -> registers: raw residuals and the caller's pi
     float l[E], ev[E], q0[E];
@@ -58,8 +61,8 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         l[j] = ok ? res[i] : __builtin_inff();
         q0[j] = ok ? wts[i] : 0.0f;
     }
-    const TbSolved s = trajb_solve<E, TB_BLOCK>(sh, wm, l, q0, ev, true, b, G, N, tol, K, out_iters, trace,
-                                                ws, dbg);
+    const TbSolved s = trajb_solve<E, TB_BLOCK>(sh, wm, l, q0, ev, true, b, G, Nall, tol, K, out_iters, trace,
+                                                ws, dbg, pt);
     // a wait that timed out (RLVI_ST_TIMEOUT: the workgroups were not all resident) leaves the
     // caller's residuals and pi as they were -- the host raises on the status; it never hands out garbage
     if (s.dead) return;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
 //  0.5 us ahead at N = 8192; it needed a whole CU per workgroup to be free and was retired.)
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
-                           float *mstep_out, double mstep_scale, int *rc) {
+                           float *mstep_out, double mstep_scale, int *rc, int64_t n_all, int sharded) {
     const int mode = tune_get("RLVI_ESTEP_TRAJB", 1);
     const int64_t nmin = tune_get("RLVI_ESTEP_TRAJB_NMIN", 4096);
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin) return 0;
@@ -93,6 +96,8 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     // must be resident at once: G = min(TB_G, what the occupancy query promises for this kernel
     // on this device, less the reduction workgroup).  Too few for the slice to fit: not applicable
     // (the iterative kernel takes over).
+    const int64_t Nall = sharded ? n_all : N;
+    PeerTable *pt = sharded ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
     int launched = 0;
 #define RLVI_TB(E_, B_)                                                                           \
     do {                                                                                          \
@@ -101,7 +106,7 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
         if (G > TB_G) G = TB_G;                                                                   \
         if (G >= TJ_MAXK && (N + G - 1) / G <= (int64_t)(E_) * (B_)) {   /* node k is reduced by workgroup k */                                  \
             *rc = launch(kern, dim3((unsigned)(G + extra)), dim3(B_), 0, st, res, wts, N, tol, maxiter, \
-                         out_iters, trace, ws, mstep_out, mstep_scale, dbg, G);                   \
+                         out_iters, trace, ws, mstep_out, mstep_scale, dbg, G, Nall, pt);         \
             launched = 1;                                                                         \
         }                                                                                         \
     } while (0)

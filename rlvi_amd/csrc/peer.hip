@@ -1,0 +1,78 @@
+// Host side of the sharded E-step's cross-GPU exchange: every rank owns one small inbox in uncached
+// device memory; the peers map it through an IPC handle and the E-step kernel's reducers write their
+// per-node totals straight into it over xGMI (no collective library call on the path).  The handles
+// travel by whatever the host program has (torch.distributed.all_gather_object in rlvi_amd.dist).
+#include <string.h>
+
+#include "rlvi_common.h"
+
+using namespace rlvi;
+
+static_assert(sizeof(hipIpcMemHandle_t) == RLVI_PEER_HANDLE_BYTES, "IPC handle size");
+
+extern "C" size_t rlvi_peer_inbox_bytes(void) { return PEER_INBOX_BYTES; }
+
+// Allocate (zeroed) an inbox on the current device.  Uncached: written by other GPUs while this one
+// polls it, so no cache on either side may hold a line of it.
+extern "C" int rlvi_peer_alloc(void **inbox) {
+    if (!inbox) return RLVI_E_NULL;
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, PEER_INBOX_BYTES, hipDeviceMallocUncached);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(p, 0, PEER_INBOX_BYTES);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+    *inbox = p;
+    return 0;
+}
+
+extern "C" int rlvi_peer_free(void *inbox) {
+    if (!inbox) return 0;
+    return (int)hipFree(inbox);
+}
+
+extern "C" int rlvi_peer_export(void *inbox, void *handle64) {
+    if (!inbox || !handle64) return RLVI_E_NULL;
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, inbox);
+    if (e != hipSuccess) return (int)e;
+    memcpy(handle64, &h, sizeof(h));
+    return 0;
+}
+
+extern "C" int rlvi_peer_open(const void *handle64, void **inbox) {
+    if (!handle64 || !inbox) return RLVI_E_NULL;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return (int)e;
+    *inbox = p;
+    return 0;
+}
+
+extern "C" int rlvi_peer_close(void *inbox) {
+    if (!inbox) return 0;
+    return (int)hipIpcCloseMemHandle(inbox);
+}
+
+// Write the peer table of a workspace: inboxes[r] = rank r's inbox as mapped in this process
+// (inboxes[rank] = the local allocation).  Resets the round counter: every rank must call this at
+// the same point of the program.  world == 1 (or inboxes == NULL) clears the table.
+extern "C" int rlvi_workspace_set_peers(void *ws, int rank, int world, void *const *inboxes, void *stream) {
+    if (!ws) return RLVI_E_NULL;
+    if (world < 1 || world > MAX_PEERS || rank < 0 || rank >= world) return RLVI_E_SHAPE;
+    if (world > 1 && !inboxes) return RLVI_E_NULL;
+    PeerTable t;
+    memset(&t, 0, sizeof(t));
+    t.world = world;
+    t.rank = rank;
+    for (int r = 0; r < world && inboxes; ++r) {
+        if (world > 1 && !inboxes[r]) return RLVI_E_NULL;
+        t.inbox[r] = (unsigned long long)(uintptr_t)inboxes[r];
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(static_cast<char *>(ws) + WS_PEER_OFF, &t, sizeof(t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(st);
+}

@@ -116,7 +116,23 @@ constexpr size_t WS_WLS_BYTES = (size_t)WLS_MAX_WG * 64 * 64 * 8;               
 // = the two halves of {sum pi*l * inv_scale, hits*100/B, sum pi*l, hits} in fp64
 constexpr size_t WS_FEREC_OFF = WS_WLS_OFF + WS_WLS_BYTES;
 constexpr size_t WS_FEREC_BYTES = (size_t)MAX_COOP_WG * 8 * 8;                  // 16 KiB
-constexpr size_t WS_SCRATCH_OFF = WS_FEREC_OFF + WS_FEREC_BYTES;
+// sharded E-step over several GPUs (estep_trajb.hip, rlvi_estep_sharded_f32): the table of the ranks'
+// inboxes as mapped into THIS process (rlvi_workspace_set_peers) and the round counter of the sharded
+// solves, which every rank advances alike
+constexpr int MAX_PEERS = 8;
+struct PeerTable {
+    int32_t world, rank;
+    uint32_t dtag;                              // last round tag used (rounds of all sharded solves so far)
+    uint32_t pad;
+    unsigned long long inbox[MAX_PEERS];        // device address of rank r's inbox; [rank] is the local one
+};
+constexpr size_t WS_PEER_OFF = WS_FEREC_OFF + WS_FEREC_BYTES;
+constexpr size_t WS_PEER_BYTES = 256;
+static_assert(sizeof(PeerTable) <= WS_PEER_BYTES, "peer table must fit its workspace region");
+// an inbox: [2 parities][64 nodes][MAX_PEERS source ranks][8 self-tagged granules], 64 KiB of
+// uncached device memory that the peers map through an IPC handle and write over xGMI
+constexpr size_t PEER_INBOX_BYTES = 2ull * 64 * MAX_PEERS * 8 * 8;
+constexpr size_t WS_SCRATCH_OFF = WS_PEER_OFF + WS_PEER_BYTES;
 
 __host__ __device__ inline size_t ws_bytes_for(int64_t max_n, int64_t max_b) {
     // scratch: two fp32 vectors of max(max_n, max_b) (fused E+M keeps l and e there)

@@ -159,7 +159,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
     TbShared<TB_BLOCK / WAVE> &sh, const TbWarm &wm, const float (&l)[E], const float (&q0)[E],
     float (&ev)[E], const bool active, const int b, const int G, const int64_t N, const float tol,
     const int K, int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
-    unsigned long long *__restrict__ dbg) {
+    unsigned long long *__restrict__ dbg, PeerTable *__restrict__ pt = nullptr) {
     int dbgi = 0;
 #define TB_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
     TB_STAMP();
@@ -173,9 +173,17 @@ __device__ __forceinline__ TbSolved trajb_solve(
     TrajState *state = reinterpret_cast<TrajState *>(wsb + WS_TRAJ_OFF);
     uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const unsigned long long spin_ticks = spin_bound(hdr);
+    // (sharded over several GPUs: a peer may legitimately be late -- another process, another stream --,
+    //  and every wait downstream of the cross-rank hop inherits its lateness: 100 x the bound)
+    const unsigned long long spin_ticks = spin_bound(hdr) * (pt != nullptr ? 100ull : 1ull);
     int xstep = 0;
     bool dead = false;
+    // sharded over several GPUs (pt != nullptr): N is the population over ALL ranks; the reducer of a
+    // node pushes this rank's total into every rank's inbox and adds up what the others pushed.
+    // ptag numbers the rounds of all sharded solves of this group: the same on every rank.
+    uint32_t ptag = pt != nullptr ? pt->dtag + 1u : 0u;
+    const int pworld = pt != nullptr ? pt->world : 1;
+    const int prank = pt != nullptr ? pt->rank : 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -392,10 +400,47 @@ __device__ __forceinline__ TbSolved trajb_solve(
                 // lane l stores granule l & 7 of replica l >> 3: one store per lane
                 static_assert(XCHG3B_REPLICAS * 8 == WAVE && TB_NV <= 8, "one granule of one replica per lane");
                 const int gq = lane & 7;
-                const float val = gq == 0 ? (float)tS : gq == 1 ? (float)tP : gq == 2 ? (float)tQ
-                                  : gq == 3 ? (float)tD : gq == 4 ? (float)tM : gq == 5 ? (float)t3
-                                  : (float)t4;
-                if (gq < nq)
+                float val = gq == 0 ? (float)tS : gq == 1 ? (float)tP : gq == 2 ? (float)tQ
+                            : gq == 3 ? (float)tD : gq == 4 ? (float)tM : gq == 5 ? (float)t3
+                            : (float)t4;
+                bool xdead = false;
+                if (pt != nullptr) {
+                    // lane = (rank r = lane >> 3, granule gq): one system-scope store into rank r's inbox
+                    // slot [round parity][node b][this rank], then this rank's own slots [..][rank r]
+                    // until every rank's granules carry this round's tag; totals in rank order (the same
+                    // tree on every rank: identical bits everywhere)
+                    const int r = lane >> 3;
+                    const bool mine = r < pworld && gq < nq;
+                    const size_t slot = ((size_t)(ptag & 1u) * TJ_MAXK + b) * MAX_PEERS;
+                    if (mine) {
+                        gu64 *dst = (gu64 *)(uintptr_t)pt->inbox[r] + (slot + prank) * 8 + gq;
+                        __hip_atomic_store(dst, ((unsigned long long)ptag << 32) | __float_as_uint(val),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    gu64 *src = (gu64 *)(uintptr_t)pt->inbox[prank] + (slot + (mine ? r : prank)) * 8 + (mine ? gq : 0);
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned long long got = 0ull;
+                    bool timeout = false;
+                    for (unsigned spin = 0;; ++spin) {
+                        got = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const bool ok = !mine || (uint32_t)(got >> 32) == ptag;
+                        if (__all(ok)) break;
+                        if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+                    }
+                    if (timeout) {
+                        if (lane == 0) { atomicOr(&hdr->status, RLVI_ST_TIMEOUT); sh.out.dead = 1; }
+                        xdead = true;
+                    }
+                    const float pv = __uint_as_float((uint32_t)got);
+                    double acc = mine ? (double)pv : (gq == 4 ? (double)__builtin_inff() : 0.0);
+#pragma unroll
+                    for (int m = 8; m < WAVE; m <<= 1) {
+                        const double o = __shfl_xor(acc, m, WAVE);
+                        acc = gq == 4 ? (o < acc ? o : acc) : acc + o;
+                    }
+                    val = (float)acc;
+                }
+                if (gq < nq && !xdead)
                     __hip_atomic_store(B + ((size_t)(lane >> 3) * TJ_MAXK + b) * XCHG3_GRANULES + gq,
                                        ((unsigned long long)tag << 32) | __float_as_uint(val),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -441,7 +486,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
                                 rn_l, shift, invN, tol, trace, true, xstep, dbg);
         }
         __syncthreads();
-        ++tag; ++xstep;
+        ++tag; ++xstep; ++ptag;
         TB_STAMP();   // recurrence done
         dead = sh.out.dead != 0;
         it = sh.out.res_it;
@@ -476,6 +521,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
             state->k = K;
             state->shift = gmin;
             state->it = it;
+            if (pt != nullptr) pt->dtag = ptag - 1u;
             __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -12,6 +12,11 @@ The reference is single-device (no distributed code at all), so the
            runs the whole fixed point redundantly (bit-identical pi everywhere, zero further
            collectives).  For N <~ 1e6 that beats 20-40 latency-bound scalar all-reduces
            (the "epsilon-prior all-reduce" of BASELINE.json, kept as `estep_allreduce_scalars`).
+           SHARDED alternative (setup_peers + ops.estep_sharded, the bench's N > 1 path): every
+           rank keeps only its own samples; the E-step kernel's reducer workgroups write their
+           per-node totals straight into the other ranks' inboxes over xGMI (IPC-mapped uncached
+           device memory) -- no gather of the residuals, no collective call, one extra hop of a few
+           microseconds per round; every rank reaches the same fixed point bit for bit.
   threshold / mask: replicated on the identical pi.
 
 Everything here is host logic on top of torch collectives and works on CPU tensors too.
@@ -196,3 +201,74 @@ def estep_allreduce_scalars(residuals_local, weights_local, n_global, tol=1e-3, 
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
     w.div_(mx)
     return it
+
+
+class Peers:
+    """The cross-GPU exchange of the sharded E-step: one inbox per rank (uncached device memory), mapped
+    into every other rank's process through an IPC handle.  Keep the object alive as long as the workspace
+    is used for sharded E-steps; close() unmaps and frees."""
+
+    def __init__(self, ws, group=None):
+        import ctypes
+        from . import _lib
+        from . import ops
+        L = _lib.load()
+        self._L = L
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if multi else 1
+        self.rank = dist.get_rank(group) if multi else 0
+        self.own, self.mapped = None, []
+        err, raw = None, None
+        try:
+            if self.world > 8:
+                raise _lib.RlviError("the sharded E-step exchanges over at most 8 ranks (one node)")
+            own = ctypes.c_void_p()
+            _lib.check(L.rlvi_peer_alloc(ctypes.byref(own)), "rlvi_peer_alloc")
+            self.own = own
+            handle = ctypes.create_string_buffer(64)
+            _lib.check(L.rlvi_peer_export(own, handle), "rlvi_peer_export")
+            raw = handle.raw
+        except Exception as e:  # noqa: BLE001  (agreed on below: every rank raises or none)
+            err = repr(e)
+        handles = [raw]
+        if multi:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, raw, group=group)
+        if err is None and all(h is not None for h in handles):
+            try:
+                ptrs = (ctypes.c_void_p * self.world)()
+                for r in range(self.world):
+                    if r == self.rank:
+                        ptrs[r] = self.own.value
+                    else:
+                        p = ctypes.c_void_p()
+                        _lib.check(L.rlvi_peer_open(handles[r], ctypes.byref(p)), "rlvi_peer_open")
+                        self.mapped.append(p)
+                        ptrs[r] = p.value
+                _lib.check(L.rlvi_workspace_set_peers(ws.ptr, self.rank, self.world, ptrs, ops._stream_ptr()),
+                           "rlvi_workspace_set_peers")
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        elif err is None:
+            err = "a peer could not export its inbox"
+        errs = [err]
+        if multi:
+            # also the barrier: nobody pushes into an inbox that is not mapped everywhere yet
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err, group=group)
+        if any(e is not None for e in errs):
+            self.close()
+            raise _lib.RlviError("peer set-up failed: " + "; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e))
+
+    def close(self):
+        for p in self.mapped:
+            self._L.rlvi_peer_close(p)
+        self.mapped = []
+        if self.own is not None:
+            self._L.rlvi_peer_free(self.own)
+            self.own = None
+
+
+def setup_peers(ws, group=None):
+    """Collective: allocate, exchange and map the inboxes and write the peer table of `ws`."""
+    return Peers(ws, group)

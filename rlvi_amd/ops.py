@@ -178,6 +178,25 @@ def mstep_reduce(scale=1.0, out=None, ws=None, device=None):
     return out
 
 
+def estep_sharded(residuals, weights, n_all, tol=1e-3, maxiter=40, iters=None, ws=None, batches=0, out=None):
+    """update_sample_weights (train_rlvi.py:14-38) with the samples sharded over the ranks: this rank's
+    slice of residuals / weights in place, n_all samples over all ranks.  A collective over the ranks of
+    the workspace's peer table (rlvi_amd.dist.setup_peers(ws) first).  Raises RlviError(RLVI_E_LIMIT)
+    when the shape is outside the trajectory kernel.  batches > 0: `out` [4] also receives this rank's
+    M-step scalars of the epoch (as epoch_end)."""
+    L = _lib.load()
+    _require_gpu(residuals, weights)
+    for t in (residuals, weights):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1:
+            raise ValueError("residuals / weights must be contiguous 1-D fp32 tensors")
+    if ws is None:
+        raise ValueError("the sharded E-step needs the workspace whose peer table was set up")
+    rc = L.rlvi_estep_sharded_f32(_ptr(residuals), _ptr(weights), weights.shape[0], int(n_all), float(tol),
+                                  int(maxiter), int(batches), _ptr(out) if batches > 0 else None, _ptr(iters),
+                                  ws.ptr, _stream_ptr())
+    _lib.check(rc, "rlvi_estep_sharded_f32")
+
+
 def epoch_end(residuals, weights, overfit=False, threshold=0, batches=0, tol=1e-3, maxiter=40,
               alpha=0.05, out=None, iters=None, ws=None):
     """train_rlvi.py:99-105 in one call: E-step over all samples, truncation when `overfit`, and

@@ -1013,10 +1013,13 @@ def test_cpp_host_program_over_the_c_abi(gpu, tmp_path):
     assert "-> ok" in p.stdout
 
 
-def test_bench_two_ranks_on_one_gpu(gpu):
-    """The N > 1 control flow of bench.py end to end on real kernels: two ranks share cuda:0, the
-    residual exchange goes through gloo (no RCCL peers on a one-GPU box); one JSON line, clean
-    device status, N = 2 x rows samples in the replicated E-step."""
+@pytest.mark.parametrize("mode", ["auto", "replicated"])
+def test_bench_two_ranks_on_one_gpu(mode, gpu):
+    """The N > 1 control flow of bench.py end to end on real kernels: two ranks share cuda:0.  auto: the
+    start-up self-check admits the sharded E-step (per-node totals through IPC-mapped inboxes, the whole
+    step captured in a hipGraph, no collective call in it); replicated: the residual exchange goes
+    through gloo (no RCCL peers on a one-GPU box) and every rank runs the E-step over N = 2 x rows
+    samples.  One JSON line, clean device status."""
     import json
     import os
     import subprocess
@@ -1026,7 +1029,8 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "32768", "--backend", "gloo",
-                        "--same-device", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300,
+                        "--same-device", "--no-cpu-baseline", "--estep-dist", mode], capture_output=True,
+                       text=True, timeout=300,
                        env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -1034,6 +1038,9 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["device_status"] == 0
     assert res["config"]["n_samples"] == 65536 and res["parts"]["estep_iters"] >= 1
+    assert res["config"]["estep_dist"] == ("sharded" if mode == "auto" else "replicated"), res["config"]
+    if mode == "auto":
+        assert res["config"]["launch"] == "hipGraph"
     assert res["value"] > 0
 
 
@@ -1140,6 +1147,111 @@ def test_train_rlvi_two_ranks_on_one_gpu_reproduces_g4(gpu):
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in results), results
+
+
+def _sharded_estep_worker(rank, world, port, q, n_local, cap):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _os.environ["MASTER_ADDR"] = "127.0.0.1"
+    _os.environ["MASTER_PORT"] = str(port)
+    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch as _torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rlvi_amd import _lib, ops as _ops, synth as _synth
+        from rlvi_amd import dist as rdist
+        if cap:
+            _lib.check(_lib.load().rlvi_tune_set(b"RLVI_COOP_CAP", cap), "tune")
+        dev = _torch.device("cuda:0")
+        N = n_local * world
+        ws = _ops.Workspace(dev, n_local, 0)
+        peers = rdist.setup_peers(ws)
+        out = []
+        lo, hi = rank * n_local, (rank + 1) * n_local
+        for (kind, seed) in (("bimodal", 1), ("bimodal", 1), ("exp", 2), ("heavy", 3), ("bimodal", 4)):
+            r_all = _synth.residual_vector(kind, N, seed=seed)
+            w_all = np.random.default_rng(seed).random(N).astype(np.float32)
+            res = _torch.from_numpy(r_all[lo:hi].copy()).to(dev)
+            w = _torch.from_numpy(w_all[lo:hi].copy()).to(dev)
+            iters = _torch.zeros(1, dtype=_torch.int32, device=dev)
+            dist.barrier()
+            _ops.estep_sharded(res, w, N, iters=iters, ws=ws)
+            _torch.cuda.synchronize()
+            out.append((res.cpu().numpy(), w.cpu().numpy(), int(iters), ws.status()))
+        dist.barrier()
+        peers.close()
+        q.put((rank, "ok", out))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + "\n" + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,n_local,cap", [(2, 32768, 0), (2, 20000, 100), (3, 16384, 80)])
+def test_sharded_estep_ranks_on_one_gpu(world, n_local, cap, gpu, oracle):
+    """SURVEY 8(e), the E-step sharded over ranks: `world` processes on cuda:0, each with its own slice of
+    the samples; the kernels' reducer workgroups push their per-node totals into the other ranks' inboxes
+    (IPC-mapped uncached device memory; over xGMI when the ranks sit on different GPUs -- one GPU here,
+    so this checks the protocol, the mapping and the arithmetic, not the fabric).  Every rank must come out
+    with its slice of the oracle's pi on the WHOLE vector, the same iteration count, a clean status --
+    cold, warm (the same vector again) and on new data."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_estep_worker, args=(r, world, port, q, n_local, cap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in results), [r[1] for r in results]
+    N = n_local * world
+    for i, (kind, seed) in enumerate((("bimodal", 1), ("bimodal", 1), ("exp", 2), ("heavy", 3), ("bimodal", 4))):
+        r_all = synth.residual_vector(kind, N, seed=seed)
+        w_all = np.random.default_rng(seed).random(N).astype(np.float32)
+        ro, wo = r_all.copy(), w_all.copy()
+        it = oracle.update_sample_weights(ro, wo)
+        res = np.concatenate([results[r][2][i][0] for r in range(world)])
+        w = np.concatenate([results[r][2][i][1] for r in range(world)])
+        assert all(results[r][2][i][2] == it for r in range(world)), (kind, [results[r][2][i][2] for r in range(world)], it)
+        assert all(results[r][2][i][3] == 0 for r in range(world))
+        assert np.array_equal(res, r_all - r_all.min())
+        rel, small = rel_pi(w, wo)
+        assert rel <= REL and small <= 1e-7
+        assert w.max() == np.float32(1.0)
+
+
+def test_sharded_estep_one_rank_is_the_plain_estep(gpu):
+    """A peer table of one rank: the same kernel path with the cross-rank hop through the local inbox;
+    bit-identical to rlvi_estep_deep_f32."""
+    torch, ops, dev = gpu
+    from rlvi_amd import dist as rdist
+    N = 65536
+    ws_a, ws_b = ops.Workspace(dev, N, 0), ops.Workspace(dev, N, 0)
+    peers = rdist.setup_peers(ws_a)
+    try:
+        for seed in (1, 1, 2):
+            r = synth.residual_vector("bimodal", N, seed=seed)
+            ra, rb = torch.from_numpy(r.copy()).to(dev), torch.from_numpy(r.copy()).to(dev)
+            wa, wb = torch.ones(N, device=dev), torch.ones(N, device=dev)
+            ia, ib = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.estep_sharded(ra, wa, N, iters=ia, ws=ws_a)
+            ops.estep_deep(rb, wb, iters=ib, ws=ws_b)
+            torch.cuda.synchronize()
+            assert int(ia) == int(ib) and torch.equal(wa, wb) and torch.equal(ra, rb)
+            assert ws_a.status() == 0
+    finally:
+        peers.close()
 
 
 @pytest.mark.parametrize("key", ["C10", "C100", "C101"])
