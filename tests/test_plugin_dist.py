@@ -174,3 +174,50 @@ def test_unequal_shards_are_refused():
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in results), results
+
+
+def _worker_peers_without_gpu(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rlvi_amd import _lib
+        from rlvi_amd import dist as rdist
+
+        class NoWs:
+            ptr = None
+        try:
+            rdist.setup_peers(NoWs())
+            q.put((rank, "FAIL no error"))
+        except _lib.RlviError as e:
+            # both ranks learn about both failures and leave the set-up together: the group still works
+            assert "rank 0" in str(e) and "rank 1" in str(e), str(e)
+            dist.barrier()
+            q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "FAIL " + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_peer_setup_fails_loudly_and_on_every_rank_without_a_gpu():
+    """The sharded E-step's inboxes are device memory: on a box without a GPU the set-up must raise the
+    same RlviError on every rank (the ranks agree on the failure before anyone leaves), never hang and
+    never fall back to anything."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_peers_without_gpu, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=100) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in results), results
