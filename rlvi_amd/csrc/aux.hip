@@ -38,6 +38,10 @@ extern "C" int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream) {
     // behind them need no initial value)
     hipError_t e = hipMemsetAsync(ws, 0, WS_WLS_OFF, st);
     if (e != hipSuccess) return (int)e;
+    // the tagged result records of the one-launch in-batch E+M (the peer table behind them is written
+    // by rlvi_workspace_set_peers only and survives a re-initialisation)
+    e = hipMemsetAsync(static_cast<char *>(ws) + WS_FEREC_OFF, 0, WS_FEREC_BYTES, st);
+    if (e != hipSuccess) return (int)e;
     // bound of every inter-workgroup wait (RLVI_SPIN_BOUND_MS, default 100 ms), in 100 MHz ticks
     const long long ms = tune_get("RLVI_SPIN_BOUND_MS", 100);
     const unsigned long long ticks = (unsigned long long)(ms > 0 ? ms : 100) * 100000ull;

@@ -23,6 +23,7 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                            float *mstep_out, double mstep_scale, int *rc, int64_t n_all = 0,
                            int sharded = 0);
+int peers_world_of(const void *ws);     // peer.hip: 0 = rlvi_workspace_set_peers never ran on it
 
 // t/(1+t) etc.: fp32 uses v_rcp_f32 (1 ulp) + multiply instead of the ~15-instruction IEEE
 // division sequence: <= 2 ulp on pi, two orders of magnitude inside the 1e-5 parity budget, and
@@ -250,6 +251,7 @@ extern "C" int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t 
     if (n_local <= 0 || n_all < n_local || maxiter < 0 || batches < 0) return RLVI_E_SHAPE;
     if (((uintptr_t)residuals & 3) || ((uintptr_t)weights & 3) || ((uintptr_t)out & 3) || ((uintptr_t)ws & 255))
         return RLVI_E_ALIGN;
+    if (peers_world_of(ws) < 1) return RLVI_E_WS;      // no peer table in this workspace
     int rc = 0;
     if (try_launch_estep_trajb(residuals, weights, n_local, tol, maxiter, out_iters, nullptr, ws,
                                static_cast<hipStream_t>(stream), out, batches > 0 ? 1.0 / (double)batches : 1.0,

@@ -4,9 +4,27 @@
 // travel by whatever the host program has (torch.distributed.all_gather_object in rlvi_amd.dist).
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "rlvi_common.h"
 
 using namespace rlvi;
+
+// Host-side record of the workspaces whose peer table has been written: rlvi_estep_sharded_f32 refuses
+// (RLVI_E_WS) a workspace that never saw rlvi_workspace_set_peers instead of launching on a table of
+// whatever the memory held.
+namespace {
+std::mutex g_mu;
+std::unordered_map<const void *, int> g_world;
+}  // namespace
+namespace rlvi {
+int peers_world_of(const void *ws) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_world.find(ws);
+    return it == g_world.end() ? 0 : it->second;
+}
+}  // namespace rlvi
 
 static_assert(sizeof(hipIpcMemHandle_t) == RLVI_PEER_HANDLE_BYTES, "IPC handle size");
 
@@ -74,5 +92,9 @@ extern "C" int rlvi_workspace_set_peers(void *ws, int rank, int world, void *con
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemcpyAsync(static_cast<char *>(ws) + WS_PEER_OFF, &t, sizeof(t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return (int)e;
-    return (int)hipStreamSynchronize(st);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_world[ws] = world;
+    return 0;
 }

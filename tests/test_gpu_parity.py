@@ -1231,6 +1231,15 @@ def test_sharded_estep_ranks_on_one_gpu(world, n_local, cap, gpu, oracle):
         assert w.max() == np.float32(1.0)
 
 
+def test_sharded_estep_refuses_a_workspace_without_a_peer_table(gpu):
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    N = 8192
+    ws = ops.Workspace(dev, N, 0)
+    with pytest.raises(_lib.RlviError):
+        ops.estep_sharded(torch.rand(N, device=dev), torch.ones(N, device=dev), N, ws=ws)
+
+
 def test_sharded_estep_one_rank_is_the_plain_estep(gpu):
     """A peer table of one rank: the same kernel path with the cross-rank hop through the local inbox;
     bit-identical to rlvi_estep_deep_f32."""
