@@ -103,6 +103,9 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
                                          unsigned long long *dbg, double tR3 = 0.0, double tR4 = 0.0) {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool has = lane < Ke;
+    // RLVI_TJ_DEBUG: where the recurrence wave's time goes (first round of workgroup 0)
+#define TJ_STAMP(k) do { if (dbg != nullptr && blockIdx.x == 0 && xstep == 0 && lane == 0) dbg[990 + (k)] = wall_clock64(); } while (0)
+    TJ_STAMP(0);
     float scale = 1.0f;
     if (FIRST) {
         gmin = group_allreduce<WAVE>(gmin, FMin());
@@ -171,11 +174,15 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
             avg_l = fmaf(b_l * rn, eps, a0_l);
         }
     }
+    TJ_STAMP(1);   // lane-parallel preparation done
     // serial chain; `step` is wave-uniform, so the per-node values come through v_readlane
     // (SGPR lane select, no LDS):  avg = a0 + b d - c d^2, d = r - r',  r <- avg / (1 - avg).
     // Fast form first (five dependent fp32 operations per step); its steps are then checked
     // lane-parallel against the trust region |r - r'| <= r'/2, 0 < avg < 1, and only a chain
     // that left it (cold or poor guesses) is redone on the global model below.
+    // (Measured: 62 ns per step = ~19 clocks per level of the seven-level dependent chain dr -> dr^2 ->
+    //  Estrin pair -> avg -> 1 - avg -> rcp -> next dr; the six v_readlane of a step already issue in its
+    //  stalls -- writing four steps per loop iteration side by side changed nothing.)
     if (!scanned) {
 #pragma unroll 1
         for (int step = 0; step < steps; ++step) {
@@ -202,6 +209,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
             r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
         }
     }
+    TJ_STAMP(2);   // serial chain done
     // (25 % trust region for the local model: inside it one more round finishes -- the bench's
     //  data-to-data drift of 2-7 % stays on this path; beyond it the local model converges one
     //  node per round at worst)
@@ -297,6 +305,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     // affine scan over the lanes.  Every stop test up to the stop index has to clear tol by a band of
     // 3 x sqrt2 E r/|h| + 2 x {2 mv^2 + |sigma dln rbar|/4 + 0.5 %}; anything inside a band: no
     // accept, the verification round runs.
+    TJ_STAMP(3);   // trust check / tail done
     int it_acc = 0;
     bool accept_now = false;
     if (HI && FIRST && __all(inside) && !scanned && round_ok && trace == nullptr && steps >= 2) {
@@ -363,6 +372,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
             if (lane == 0) dbg[699] = ((unsigned long long)(accept_now ? 1 : 0) << 32) | (unsigned)it_acc;
         }
     }
+    TJ_STAMP(4);   // acceptance test done
     // Early accept: with nodes off by delta the corrected r are good to 0.25 delta^2, and the
     // errors (evaluated AT the nodes) to about delta*(r_k + r_{k-1})/|r_k - r_{k-1}| relative.
     // If every stop test up to `it` clears tol by 8x that margin, the stop index cannot change
@@ -407,6 +417,8 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         if (FIRST) out.res_min = gmin;
         out.dead = dead ? 1 : 0;
     }
+    TJ_STAMP(5);
+#undef TJ_STAMP
 }
 
 }  // namespace rlvi

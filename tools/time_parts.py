@@ -158,5 +158,7 @@ with torch.cuda.stream(side):
         ee = full[764:828]
         print("  E_k    :", np.array(ee >> 32, np.uint32).view(np.float32)[:24])
         print("  slope  :", np.array(ee & 0xFFFFFFFF, np.uint32).view(np.float32)[:24])
+        cs = full[990:996].astype(np.int64)
+        print("recurrence wave [entry, prepared, chain, trust/tail, acceptance, out] us:", [round(float(v - cs[0]) / 100.0, 2) for v in cs])
         print("rounds (it, delta):", [(int(x >> 32), float(np.array([x & 0xFFFFFFFF], np.uint32).view(np.float32)[0])) for x in rd if x][:12])
     print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
