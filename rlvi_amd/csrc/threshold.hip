@@ -21,13 +21,14 @@
 namespace rlvi {
 
 constexpr int THR_BLOCK = 1024;
-constexpr int THR_NW = THR_BLOCK / WAVE;
 
 struct Red3 { double s; unsigned long long a, b; };
 
 // Block-wide reduce of {sum (fp64), min (u64), max (u64)}; every thread gets the result.
+template <int BLOCK>
 __device__ __forceinline__ Red3 block_reduce3(double s, unsigned long long mn,
                                               unsigned long long mx) {
+    constexpr int THR_NW = BLOCK / WAVE;
     __shared__ double sh_s[THR_NW];
     __shared__ unsigned long long sh_a[THR_NW], sh_b[THR_NW];
     __shared__ Red3 sh_out;
@@ -53,7 +54,7 @@ __device__ __forceinline__ Red3 block_reduce3(double s, unsigned long long mn,
 }
 
 // E > 0: keys live in registers (N <= 1024*E).  E == 0: keys are re-read from memory per pass.
-template <int E>
+template <int E, int THR_BLOCK>
 struct Keys {
     uint32_t k[E > 0 ? E : 1];
     const float *w;
@@ -88,15 +89,14 @@ __device__ __forceinline__ double one_minus(uint32_t key) {
     return (double)(1.0f - key_f32(key));   // fp32 subtraction, as `1 - sorted_weights`
 }
 
-template <int E, bool TRUNC>
-__global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict__ w, int64_t N,
-                                                              float alpha,
-                                                              float *__restrict__ thr_io,
-                                                              uint8_t *__restrict__ mask,
-                                                              int64_t *__restrict__ kept_out,
-                                                              const int32_t *__restrict__ only_if) {
-    if (only_if != nullptr && *only_if == 0) return;     // the fast form already did the work
-    Keys<E> keys;
+// The generic form: any fp32 values (negative, > 1, NaN ordered last), fp64 prefix sums, a bisection
+// on the key -- one workgroup of BLOCK threads.  The product path for N > 2 097 152 and the in-kernel
+// hand-over of the radix descent when a weight lies outside [0, 1].
+template <int E, bool TRUNC, int BLOCK>
+__device__ __forceinline__ void threshold_generic(float *__restrict__ w, int64_t N, float alpha,
+                                                  float *__restrict__ thr_io, uint8_t *__restrict__ mask,
+                                                  int64_t *__restrict__ kept_out) {
+    Keys<E, BLOCK> keys;
     keys.load(w, N);
 
     // beta = alpha * sum(1 - w)   (train_rlvi.py:43-44); global min / max key
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
         kmin = k < kmin ? k : kmin;
         kmax = k > kmax ? k : kmax;
     });
-    Red3 r = block_reduce3(tot, kmin, kmax);
+    Red3 r = block_reduce3<BLOCK>(tot, kmin, kmax);
     const float beta = (float)r.s * alpha;
     kmin = r.a;
     kmax = r.b;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
         const unsigned long long mid = lo + ((hi - lo) >> 1);
         double s = 0.0;
         keys.for_each([&](uint32_t k, int64_t) { s += (k >= mid) ? one_minus(k) : 0.0; });
-        r = block_reduce3(s, 0ull, 0ull);
+        r = block_reduce3<BLOCK>(s, 0ull, 0ull);
         if ((float)r.s <= beta) hi = mid; else lo = mid + 1ull;
     }
     const unsigned long long cstar = lo;
@@ -138,11 +138,11 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
             below = (k + 1ull) > below ? (k + 1ull) : below;
         }
     });
-    r = block_reduce3(s_in, above, below);
+    r = block_reduce3<BLOCK>(s_in, above, below);
     const double S = r.s;
     above = r.a;
     below = r.b;
-    r = block_reduce3(n_in, 0ull, 0ull);
+    r = block_reduce3<BLOCK>(n_in, 0ull, 0ull);
     const double cnt_in = r.s;
 
     float thr;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
         const uint32_t v = (uint32_t)(below - 1ull);
         double mult = 0.0;
         keys.for_each([&](uint32_t k, int64_t) { mult += (k == v) ? 1.0 : 0.0; });
-        r = block_reduce3(mult, 0ull, 0ull);
+        r = block_reduce3<BLOCK>(mult, 0ull, 0ull);
         // j = #{i in 1..mult : fl32(S + i*t) <= beta}; monotone in i -> binary search
         const double t = one_minus(v);
         long long jl = 0, jh = (long long)r.s;   // P(jl) true, P(jh) false (minimality of c*)
@@ -184,9 +184,18 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
             if (mask != nullptr) mask[i] = m ? 1 : 0;
             kept += m ? 1.0 : 0.0;
         });
-        r = block_reduce3(kept, 0ull, 0ull);
+        r = block_reduce3<BLOCK>(kept, 0ull, 0ull);
         if (threadIdx.x == 0 && kept_out != nullptr) *kept_out = (int64_t)r.s;
     }
+}
+
+template <int E, bool TRUNC>
+__global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict__ w, int64_t N,
+                                                              float alpha,
+                                                              float *__restrict__ thr_io,
+                                                              uint8_t *__restrict__ mask,
+                                                              int64_t *__restrict__ kept_out) {
+    threshold_generic<E, TRUNC, THR_BLOCK>(w, N, alpha, thr_io, mask, kept_out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -204,8 +213,10 @@ __global__ __launch_bounds__(THR_BLOCK) void threshold_kernel(float *__restrict_
 // exchanges instead of the ~20 dependent ones of a bisection (71 us at N = 65 536), the same exact
 // arithmetic, the same bits.  After the last pass the bin below IS the reference's "next key
 // below" (v, with its multiplicity), and the smallest key above comes from the min field.
-// Outside [0, 1] (NaN, -0.0, negative, > 1): *fallback = 1 and the generic fp64 kernel above runs
-// in the same stream.  G <= 256 workgroups of 256 threads, all provably co-resident (launcher);
+// Outside [0, 1] (NaN, -0.0, negative, > 1): every workgroup leaves the descent at its first exchange
+// and workgroup 0 runs the generic fp64 form above on the whole vector, in the same launch (round 1
+// enqueued the generic kernel behind this one on a flag: a kernel boundary, 2 us, on every call for a
+// case that never happens to an E-step's output).  G <= 256 workgroups of 256 threads, all provably co-resident (launcher);
 // G == 1 needs no exchange at all.
 // ---------------------------------------------------------------------------------------
 constexpr int THQ_BLOCK = 256;
@@ -411,10 +422,11 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
 template <int E, bool TRUNC>
 __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     float *__restrict__ w, int64_t N, float alpha, float *__restrict__ thr_io,
-    uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out, int32_t *__restrict__ fallback,
+    uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out,
     void *ws, unsigned long long *__restrict__ dbg, int use_state) {
     __shared__ ThqShared sh;
     int dbgi = 0;
+    bool hand_over = false;
     THQ_STAMP();
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int b = (int)blockIdx.x, G = (int)gridDim.x;
@@ -617,15 +629,11 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         ok = spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi)
                   : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
         ++tag; ++xstep;
-        if (!ok) {
-            if (level == 0 && b == 0 && tid == 0) *fallback = 0;
-            break;
-        }
+        if (!ok) break;
         if (level == 0) {
-            // out of [0, 1]: the generic kernel (enqueued behind this one) takes over
+            // out of [0, 1]: the generic form (workgroup 0, below) takes over
             const bool range_bad = sh.h[0].cnt[THR_BINS - 1] != 0u;
-            if (b == 0 && tid == 0) *fallback = range_bad ? 1 : 0;
-            if (range_bad) { ok = false; break; }
+            if (range_bad) { ok = false; hand_over = true; break; }
         }
         const int b1 = descend(0, level == 0, coarse ? (int)gbin : -1);
         if (b1 == 0) {
@@ -707,6 +715,10 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         }
         __hip_atomic_store((gu32 *)&hdr->epoch_base, tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (hand_over && b == 0) {       // (nobody has written anything: every workgroup left at the first exchange)
+        __syncthreads();
+        threshold_generic<0, TRUNC, THQ_BLOCK>(w, N, alpha, thr_io, mask, kept_out);
+    }
 }
 
 __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, int64_t N,
@@ -721,13 +733,11 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
 }
 
 // Every N up to 2 097 152: the radix descent on G = min(256, N / 256, what is provably co-resident)
-// workgroups, handing over to the generic fp64 form (any range) by setting a flag the generic kernel
-// reads at its start -- both are enqueued, the second is a no-op when the first one did the work.
-// Larger: one workgroup, streaming.
+// workgroups (its workgroup 0 runs the generic fp64 form itself when a weight lies outside [0, 1]).
+// Larger: the generic form, one workgroup, streaming.
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
                             int64_t *kept, void *ws, hipStream_t st) {
-    int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + WS_SCRATCH_OFF);
     unsigned long long *dbg = tune_get("RLVI_THR_DEBUG", 0)
                                   ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF + 256)
                                   : nullptr;
@@ -741,10 +751,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
         if (!launched && (g_ == 1 || coop_cap(kern, THQ_BLOCK) >= g_) &&                           \
             (N + g_ - 1) / g_ <= (int64_t)(E_) * THQ_BLOCK) {                                      \
             rc = launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask,     \
-                        kept, flag, ws, dbg, use_state);                                         \
-            if (rc == 0)                                                                         \
-                rc = launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, \
-                            thr, mask, kept, (const int32_t *)flag);                             \
+                        kept, ws, dbg, use_state);                                               \
             launched = true;                                                                     \
         }                                                                                        \
     } while (0)
@@ -780,7 +787,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
 #undef RLVI_THQ
     if (launched) return rc;
     return launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, thr, mask,
-                  kept, (const int32_t *)nullptr);
+                  kept);
 }
 
 }  // namespace rlvi
