@@ -127,7 +127,7 @@ int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol, 
  * for bit and writes pi / the min-shifted residuals of its own samples.  No collective-library call
  * and no gather of the residual vector on the path.
  *
- *   rlvi_peer_alloc / _export / _open / _close / _free   one 64-KiB inbox per rank in uncached device
+ *   rlvi_peer_alloc / _export / _open / _close / _free   one 320-KiB inbox per rank in uncached device
  *       memory, exchanged as 64-byte IPC handles by the host program (rlvi_amd.dist.setup_peers)
  *   rlvi_workspace_set_peers(ws, rank, world, inboxes, stream)   inboxes[r] = rank r's inbox as mapped
  *       in this process; call at the same program point on every rank (resets the round counter)
@@ -148,6 +148,14 @@ int rlvi_workspace_set_peers(void *ws, int rank, int world, void *const *inboxes
 int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t n_local, int64_t n_all,
                            float tol, int maxiter, int64_t batches, float *out, int32_t *out_iters,
                            void *ws, void *stream);
+/* The type-II threshold + truncation (train_rlvi.py:41-49,:102-103) on weights sharded the same way:
+ * the radix descent's per-bin totals take the same route through the inboxes (exact integers, so
+ * bit-exact as on one device); *thr_inout and *kept_out (over ALL ranks) are identical on every rank,
+ * the truncation and mask_gt cover this rank's n_local weights.  RLVI_E_LIMIT for n_local <= 1024;
+ * a weight outside [0, 1] raises RLVI_ST_NOCONV (the one-device generic form cannot see the others). */
+int rlvi_threshold_truncate_sharded_f32(float *weights, int64_t n_local, int64_t n_all, float alpha,
+                                        float *thr_inout, uint8_t *mask_gt, int64_t *kept_out,
+                                        void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * End of an epoch in one call, replaces train_rlvi.py:99-105: update_sample_weights over all N

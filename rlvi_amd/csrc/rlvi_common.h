@@ -129,9 +129,12 @@ struct PeerTable {
 constexpr size_t WS_PEER_OFF = WS_FEREC_OFF + WS_FEREC_BYTES;
 constexpr size_t WS_PEER_BYTES = 256;
 static_assert(sizeof(PeerTable) <= WS_PEER_BYTES, "peer table must fit its workspace region");
-// an inbox: [2 parities][64 nodes][MAX_PEERS source ranks][8 self-tagged granules], 64 KiB of
-// uncached device memory that the peers map through an IPC handle and write over xGMI
-constexpr size_t PEER_INBOX_BYTES = 2ull * 64 * MAX_PEERS * 8 * 8;
+// an inbox (uncached device memory that the peers map through an IPC handle and write over xGMI):
+// E-step part [2 parities][64 nodes][MAX_PEERS source ranks][8 self-tagged granules] = 64 KiB, then the
+// threshold part [2 parities][512 records][MAX_PEERS source ranks][4 granules] = 256 KiB
+constexpr size_t PEER_ESTEP_BYTES = 2ull * 64 * MAX_PEERS * 8 * 8;
+constexpr size_t PEER_THR_BYTES = 2ull * 512 * MAX_PEERS * 4 * 8;
+constexpr size_t PEER_INBOX_BYTES = PEER_ESTEP_BYTES + PEER_THR_BYTES;
 constexpr size_t WS_SCRATCH_OFF = WS_PEER_OFF + WS_PEER_BYTES;
 
 __host__ __device__ inline size_t ws_bytes_for(int64_t max_n, int64_t max_b) {

@@ -288,11 +288,14 @@ __device__ __forceinline__ bool thq_load(gu64 *p, uint32_t tag, uint32_t &cnt, u
 // Record r = half * 256 + bin lives at slot r of the stage-A row of its workgroup.
 // (stamps go to LDS and are copied out at the end: a global store in front of a barrier would cost its round trip)
 #define THQ_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) sh.stamps[dbgi++] = wall_clock64(); } while (0)
+// pt != nullptr (sharded over several GPUs): the bin's publishing wave first pushes this rank's totals
+// into every rank's inbox, adds up what all ranks pushed (integers: exact, order-free) and publishes the
+// global totals; ptag numbers the sharded exchanges of the group (rlvi_trajb.h uses the same counter).
 template <int NH>
 __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bufB, uint32_t tag,
                                              int xstep, int G, WsHeader *hdr,
                                              unsigned long long spin_ticks, unsigned long long *dbg,
-                                             int &dbgi) {
+                                             int &dbgi, PeerTable *pt = nullptr, uint32_t ptag = 0u) {
     if (G == 1) return true;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int b = (int)blockIdx.x;
@@ -371,8 +374,47 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
                     tc += sh.wcnt[hf * THQ_NW + w]; ts += sh.wsum[hf * THQ_NW + w];
                     tm = sh.wmin[hf * THQ_NW + w] < tm ? sh.wmin[hf * THQ_NW + w] : tm;
                 }
+                if (pt != nullptr) {
+                    // lane = (rank r = rep, granule gq): push, poll, add (the sum's halves are rejoined first)
+                    const int r = rep, pworld = pt->world, prank = pt->rank;
+                    const bool mine = r < pworld;
+                    const uint32_t mv = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
+                                                                                : (uint32_t)(ts >> 32);
+                    const size_t slot = ((size_t)(ptag & 1u) * NREC + hf * THR_BINS + bin) * MAX_PEERS;
+                    if (mine) {
+                        gu64 *dst = (gu64 *)(uintptr_t)(pt->inbox[r] + PEER_ESTEP_BYTES) + (slot + prank) * 4 + gq;
+                        __hip_atomic_store(dst, ((unsigned long long)ptag << 32) | mv, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    gu64 *src = (gu64 *)(uintptr_t)(pt->inbox[prank] + PEER_ESTEP_BYTES) + (slot + (mine ? r : prank)) * 4 + gq;
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned long long got = 0ull;
+                    bool timeout = false;
+                    for (unsigned spin = 0;; ++spin) {
+                        got = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const bool ok = !mine || (uint32_t)(got >> 32) == ptag;
+                        // (lanes 0..31 of this wave: the others have left the branch)
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+                    }
+                    if (timeout) sh.dead = 1;
+                    const uint32_t pv = (uint32_t)got;
+                    const uint32_t hi = (uint32_t)__shfl_down((int)pv, 1, WAVE);          // gq == 2: the hi half sits one lane up
+                    unsigned long long acc = !mine ? (gq == 1 ? 0xFFFFFFFFull : 0ull)
+                                             : gq == 2 ? (((unsigned long long)hi << 32) | pv) : (unsigned long long)pv;
+#pragma unroll
+                    for (int m = 4; m < 32; m <<= 1) {
+                        const unsigned long long o = __shfl_xor(acc, m, WAVE);
+                        acc = gq == 1 ? (o < acc ? o : acc) : acc + o;
+                    }
+                    // (each lane uses the one its granule needs; the total's hi half comes from the gq == 2
+                    //  lane -- shuffled by ALL lanes: a lane switched off in a branch reads as 0)
+                    const unsigned long long from_below = __shfl_up(acc, 1, WAVE);
+                    tc = acc; tm = (uint32_t)acc; ts = gq == 3 ? from_below : acc;
+                }
                 const uint32_t v = gq == 0 ? (uint32_t)tc : gq == 1 ? tm : gq == 2 ? (uint32_t)ts
                                                                            : (uint32_t)(ts >> 32);
+                if (sh.dead == 0)
                 __hip_atomic_store(B + ((size_t)rep * NREC + hf * THR_BINS + bin) * XCHG4_GRANULES + gq,
                                    ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -423,7 +465,9 @@ template <int E, bool TRUNC>
 __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     float *__restrict__ w, int64_t N, float alpha, float *__restrict__ thr_io,
     uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out,
-    void *ws, unsigned long long *__restrict__ dbg, int use_state) {
+    void *ws, unsigned long long *__restrict__ dbg, int use_state, int64_t Nall, PeerTable *__restrict__ pt) {
+    // (sharded over several GPUs: N weights here, Nall over all ranks, pt the peers' inboxes; the threshold,
+    //  the kept count and the warm-start key come out the same on every rank; otherwise Nall == N, pt == nullptr)
     __shared__ ThqShared sh;
     int dbgi = 0;
     bool hand_over = false;
@@ -437,12 +481,13 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     ThrState *state = reinterpret_cast<ThrState *>(wsb + WS_THRSTATE_OFF);
     uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const unsigned long long spin_ticks = spin_bound(hdr);
+    const unsigned long long spin_ticks = spin_bound(hdr) * (pt != nullptr ? 100ull : 1ull);
+    uint32_t ptag = pt != nullptr ? pt->dtag + 1u : 0u;
     int xstep = 0;
     if (tid == 0) sh.dead = 0;
     // (read before the first exchange: workgroup 0 overwrites them after the last one)
     const float prev = TRUNC ? *thr_io : 0.0f;
-    const bool warm = use_state != 0 && state->valid != 0u && state->n == (long long)N;
+    const bool warm = use_state != 0 && state->valid != 0u && state->n == (long long)Nall;
     const uint32_t guess = state->key;                   // the last call's v: its bytes are this call's guesses
 
     const int64_t L = (N + G - 1) / G;
@@ -626,9 +671,9 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         }
         __syncthreads();
         THQ_STAMP();   // histograms built
-        ok = spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi)
-                  : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
-        ++tag; ++xstep;
+        ok = spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
+                  : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
+        ++tag; ++xstep; ++ptag;
         if (!ok) break;
         if (level == 0) {
             // out of [0, 1]: the generic form (workgroup 0, below) takes over
@@ -697,8 +742,8 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
             const unsigned long long kw = wave_sum((unsigned long long)kept);
             if (lane == 0) atomicAdd(&sh.h[0].sum[0], kw);
             __syncthreads();
-            ok = thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
-            ++tag; ++xstep;
+            ok = thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
+            ++tag; ++xstep; ++ptag;
             if (ok && b == 0 && tid == 0) *kept_out = (int64_t)sh.h[0].sum[0];
         }
     }
@@ -706,8 +751,9 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     if (b == 0 && tid == 0) {
         if (ok) *thr_io = thr;
         // this call's v for the next call's guesses (every workgroup read the old one before its first exchange)
-        state->n = (long long)N;
+        state->n = (long long)Nall;
         state->key = prefix;
+        if (pt != nullptr) pt->dtag = ptag - 1u;
         state->valid = (ok && !all_inside) ? 1u : 0u;
         if (dbg != nullptr) {
             for (int q = 0; q < dbgi; ++q) dbg[q] = sh.stamps[q];
@@ -717,7 +763,13 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     }
     if (hand_over && b == 0) {       // (nobody has written anything: every workgroup left at the first exchange)
         __syncthreads();
-        threshold_generic<0, TRUNC, THQ_BLOCK>(w, N, alpha, thr_io, mask, kept_out);
+        if (pt != nullptr) {
+            // sharded: the generic form sees one rank's weights only -- report instead (every rank saw the
+            // same totals, so every rank lands here)
+            if (tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
+        } else {
+            threshold_generic<0, TRUNC, THQ_BLOCK>(w, N, alpha, thr_io, mask, kept_out);
+        }
     }
 }
 
@@ -737,7 +789,9 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
 // Larger: the generic form, one workgroup, streaming.
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
-                            int64_t *kept, void *ws, hipStream_t st) {
+                            int64_t *kept, void *ws, hipStream_t st, int64_t n_all = 0, int sharded = 0) {
+    const int64_t Nall = sharded ? n_all : N;
+    PeerTable *pt = sharded ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
     unsigned long long *dbg = tune_get("RLVI_THR_DEBUG", 0)
                                   ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF + 256)
                                   : nullptr;
@@ -751,7 +805,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
         if (!launched && (g_ == 1 || coop_cap(kern, THQ_BLOCK) >= g_) &&                           \
             (N + g_ - 1) / g_ <= (int64_t)(E_) * THQ_BLOCK) {                                      \
             rc = launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask,     \
-                        kept, ws, dbg, use_state);                                               \
+                        kept, ws, dbg, use_state, Nall, pt);                                     \
             launched = true;                                                                     \
         }                                                                                        \
     } while (0)
@@ -760,7 +814,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
     // that many workgroups are co-resident on this device
     if (tune_get("RLVI_THR_RADIX", 1)) {
         const int force_g = tune_get("RLVI_THR_G", 0);
-        if (N <= 1024 && !force_g) RLVI_THQ(4, 1);
+        if (N <= 1024 && !force_g && !sharded) RLVI_THQ(4, 1);
         // the histogram costs about 1 us per key slot of a thread (LDS atomics), an exchange grows with
         // the number of publishing workgroups: 64 workgroups up to one key per thread, 128 up to four,
         // then 256 (measured at N = 65 536: 26.3 / 25.5 / 29.8 us for 64 / 128 / 256)
@@ -782,10 +836,11 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
             if (L <= THQ_BLOCK * 8) RLVI_THQ(8, G);
             else if (L <= THQ_BLOCK * 32) RLVI_THQ(32, G);
         }
-        if (N <= 8192) RLVI_THQ(32, 1);          // (fewer than 64 co-resident workgroups: one workgroup)
+        if (N <= 8192 && !sharded) RLVI_THQ(32, 1);          // (fewer than 64 co-resident workgroups: one workgroup)
     }
 #undef RLVI_THQ
     if (launched) return rc;
+    if (sharded) return RLVI_E_LIMIT;            // (the one-workgroup forms see one rank's weights only)
     return launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, thr, mask,
                   kept);
 }
@@ -814,6 +869,25 @@ extern "C" int rlvi_threshold_truncate_f32(float *weights, int64_t N, float alph
         return RLVI_E_ALIGN;
     return launch_threshold<true>(weights, N, alpha, thr_inout, mask_gt, kept_out, ws,
                                   static_cast<hipStream_t>(stream));
+}
+
+// Sharded over the GPUs of one node (rlvi_estep_sharded_f32's companion): this rank's n_local weights,
+// n_all over all ranks.  *thr_inout = max(*thr_inout, criterion over ALL weights) and *kept_out = the
+// number of weights above it over ALL ranks come out identical everywhere; the truncation and the mask
+// cover this rank's weights.  A collective; RLVI_E_LIMIT outside 1024 < n_local <= 2 097 152.
+namespace rlvi { int peers_world_of(const void *ws); }
+extern "C" int rlvi_threshold_truncate_sharded_f32(float *weights, int64_t n_local, int64_t n_all, float alpha,
+                                                   float *thr_inout, uint8_t *mask_gt, int64_t *kept_out,
+                                                   void *ws, void *stream) {
+    if (!weights || !thr_inout || !ws) return RLVI_E_NULL;
+    if (n_local <= 0 || n_all < n_local) return RLVI_E_SHAPE;
+    if (n_all > (1ll << 29)) return RLVI_E_LIMIT;
+    if (((uintptr_t)weights & 3) || ((uintptr_t)thr_inout & 3) || ((uintptr_t)kept_out & 7))
+        return RLVI_E_ALIGN;
+    if (peers_world_of(ws) < 1) return RLVI_E_WS;
+    if (n_local <= 1024) return RLVI_E_LIMIT;
+    return launch_threshold<true>(weights, n_local, alpha, thr_inout, mask_gt, kept_out, ws,
+                                  static_cast<hipStream_t>(stream), n_all, 1);
 }
 
 extern "C" int rlvi_truncate_f32(float *weights, int64_t N, const float *thr, uint8_t *mask_gt,

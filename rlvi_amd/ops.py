@@ -197,6 +197,25 @@ def estep_sharded(residuals, weights, n_all, tol=1e-3, maxiter=40, iters=None, w
     _lib.check(rc, "rlvi_estep_sharded_f32")
 
 
+def threshold_truncate_sharded(weights, n_all, threshold, alpha=0.05, want_mask=False, ws=None):
+    """threshold_truncate on weights sharded over the ranks (the companion of estep_sharded): the
+    criterion over ALL ranks' weights, max(threshold, criterion), truncation of this rank's weights.
+    Returns (threshold, mask of this rank's weights or None, kept over all ranks) -- rank-identical."""
+    L = _lib.load()
+    _require_gpu(weights)
+    if weights.dtype != torch.float32 or not weights.is_contiguous() or weights.dim() != 1:
+        raise ValueError("weights must be a contiguous 1-D fp32 tensor")
+    if ws is None:
+        raise ValueError("the sharded threshold needs the workspace whose peer table was set up")
+    thr = torch.as_tensor(threshold, dtype=torch.float32, device=weights.device).reshape(1).clone()
+    mask = torch.empty(weights.shape[0], dtype=torch.uint8, device=weights.device) if want_mask else None
+    kept = torch.zeros(1, dtype=torch.int64, device=weights.device)
+    _lib.check(L.rlvi_threshold_truncate_sharded_f32(_ptr(weights), weights.shape[0], int(n_all), float(alpha),
+                                                     _ptr(thr), _ptr(mask), _ptr(kept), ws.ptr, _stream_ptr()),
+               "rlvi_threshold_truncate_sharded_f32")
+    return thr.reshape(()), (mask.bool() if want_mask else None), kept.reshape(())
+
+
 def epoch_end(residuals, weights, overfit=False, threshold=0, batches=0, tol=1e-3, maxiter=40,
               alpha=0.05, out=None, iters=None, ws=None):
     """train_rlvi.py:99-105 in one call: E-step over all samples, truncation when `overfit`, and

@@ -1180,7 +1180,17 @@ def _sharded_estep_worker(rank, world, port, q, n_local, cap):
             dist.barrier()
             _ops.estep_sharded(res, w, N, iters=iters, ws=ws)
             _torch.cuda.synchronize()
-            out.append((res.cpu().numpy(), w.cpu().numpy(), int(iters), ws.status()))
+            w_pi = w.cpu().numpy().copy()
+            # the type-II threshold + truncation on the sharded pi (twice: the second call guesses from the first)
+            thr, mask, kept = _ops.threshold_truncate_sharded(w, N, 0.0, want_mask=True, ws=ws)
+            w2 = _torch.from_numpy(w_pi.copy()).to(dev)
+            thr2, mask2, kept2 = _ops.threshold_truncate_sharded(w2, N, 0.0, want_mask=True, ws=ws)
+            _torch.cuda.synchronize()
+            same = (float(thr2) == float(thr), int(kept2) == int(kept), bool(_torch.equal(mask, mask2)),
+                    bool(_torch.equal(w, w2)))
+            assert all(same), (kind, seed, float(thr), float(thr2), int(kept), int(kept2), same, ws.status())
+            out.append((res.cpu().numpy(), w_pi, int(iters), ws.status(), float(thr), mask.cpu().numpy(),
+                        int(kept), w.cpu().numpy()))
         dist.barrier()
         peers.close()
         q.put((rank, "ok", out))
@@ -1199,7 +1209,8 @@ def test_sharded_estep_ranks_on_one_gpu(world, n_local, cap, gpu, oracle):
     (IPC-mapped uncached device memory; over xGMI when the ranks sit on different GPUs -- one GPU here,
     so this checks the protocol, the mapping and the arithmetic, not the fabric).  Every rank must come out
     with its slice of the oracle's pi on the WHOLE vector, the same iteration count, a clean status --
-    cold, warm (the same vector again) and on new data."""
+    cold, warm (the same vector again) and on new data -- and the sharded threshold / truncation on that pi
+    with the oracle's threshold, mask and kept count bit for bit."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -1229,6 +1240,15 @@ def test_sharded_estep_ranks_on_one_gpu(world, n_local, cap, gpu, oracle):
         rel, small = rel_pi(w, wo)
         assert rel <= REL and small <= 1e-7
         assert w.max() == np.float32(1.0)
+        # threshold / mask / kept on the GPUs' own pi: bit-exact against the oracle on the whole vector,
+        # identical on every rank
+        thr_o = oracle.false_negative_criterion(w)
+        w_t = w.copy()
+        mask_o = oracle.truncate(w_t, thr_o)
+        assert all(results[r][2][i][4] == float(thr_o) for r in range(world)), (kind, [results[r][2][i][4] for r in range(world)], float(thr_o))
+        assert all(results[r][2][i][6] == int(mask_o.sum()) for r in range(world))
+        assert np.array_equal(np.concatenate([results[r][2][i][5] for r in range(world)]), mask_o.astype(bool))
+        assert np.array_equal(np.concatenate([results[r][2][i][7] for r in range(world)]), w_t)
 
 
 def test_sharded_estep_refuses_a_workspace_without_a_peer_table(gpu):
