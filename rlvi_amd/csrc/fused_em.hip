@@ -372,14 +372,15 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
     do {                                                                                             \
         auto kern = fused_em_kernel<K_, X_>;                                                         \
         const size_t lds = (size_t)FE_WAVES * FE_TPW * (K_) * 1024;                                  \
-        static bool attr_set = false;                                                                \
-        if (!attr_set) {                                                                             \
+        /* > 64 KiB of dynamic LDS has to be asked for, once per device of this process */          \
+        static int attr_dev = -1;                                                                    \
+        int cur_dev = 0;                                                                             \
+        if (hipGetDevice(&cur_dev) != hipSuccess) break;                                             \
+        if (attr_dev != cur_dev) {                                                                   \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-                (void)hipGetLastError();                                                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
                 break;                                                                               \
-            }                                                                                        \
-            attr_set = true;                                                                         \
+            attr_dev = cur_dev;                                                                      \
         }                                                                                            \
         if (coop_cap(kern, FE_THREADS, lds) < G) break;     /* all G workgroups must be resident */  \
         *rc = launch(kern, dim3((unsigned)G), dim3(FE_THREADS), lds, st, logits, labels, loss_rows, pi, B, \
