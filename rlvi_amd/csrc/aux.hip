@@ -23,6 +23,7 @@ extern "C" size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b) {
 }
 
 namespace rlvi {
+void peers_forget(const void *ws);      // peer.hip
 __global__ void ws_header_kernel(WsHeader *hdr, unsigned long long spin_ticks, int clear_status) {
     if (clear_status) hdr->status = 0;
     else hdr->spin_ticks = spin_ticks;
@@ -38,10 +39,11 @@ extern "C" int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream) {
     // behind them need no initial value)
     hipError_t e = hipMemsetAsync(ws, 0, WS_WLS_OFF, st);
     if (e != hipSuccess) return (int)e;
-    // the tagged result records of the one-launch in-batch E+M (the peer table behind them is written
-    // by rlvi_workspace_set_peers only and survives a re-initialisation)
-    e = hipMemsetAsync(static_cast<char *>(ws) + WS_FEREC_OFF, 0, WS_FEREC_BYTES, st);
+    // the tagged result records of the one-launch in-batch E+M and the peer table behind them (a
+    // workspace is not set up for sharded calls until rlvi_workspace_set_peers has run on it AFTER this)
+    e = hipMemsetAsync(static_cast<char *>(ws) + WS_FEREC_OFF, 0, WS_FEREC_BYTES + WS_PEER_BYTES, st);
     if (e != hipSuccess) return (int)e;
+    peers_forget(ws);
     // bound of every inter-workgroup wait (RLVI_SPIN_BOUND_MS, default 100 ms), in 100 MHz ticks
     const long long ms = tune_get("RLVI_SPIN_BOUND_MS", 100);
     const unsigned long long ticks = (unsigned long long)(ms > 0 ? ms : 100) * 100000ull;

@@ -24,6 +24,11 @@ int peers_world_of(const void *ws) {
     auto it = g_world.find(ws);
     return it == g_world.end() ? 0 : it->second;
 }
+// rlvi_workspace_init: whatever lived at this address before is gone, and so is its peer table
+void peers_forget(const void *ws) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_world.erase(ws);
+}
 }  // namespace rlvi
 
 static_assert(sizeof(hipIpcMemHandle_t) == RLVI_PEER_HANDLE_BYTES, "IPC handle size");

@@ -50,6 +50,25 @@ def ragged():
     return _RAGGED
 
 
+_OWNER = None
+
+
+def set_owner_sharding(owned, ws, peers):
+    """Opt in to the collective-free epoch end of train_rlvi: every rank owns a FIXED set of samples
+    (`owned`: 1-D int64 device tensor of their indexes; every sample owned by exactly one rank; the rank's
+    loader yields only those) and keeps residuals / weights of its own samples only.  The E-step and the
+    threshold then run sharded (ops.estep_sharded / threshold_truncate_sharded on the compacted owned
+    entries: the kernels exchange their totals through `peers`' inboxes), nothing is gathered, and after
+    the call only the OWNED entries of residuals / weights are meaningful on a rank.  `ws`: the workspace
+    `peers = setup_peers(ws)` was set up on.  None switches back to the replicated form."""
+    global _OWNER
+    _OWNER = None if owned is None else (owned, ws, peers)
+
+
+def owner_sharding():
+    return _OWNER
+
+
 def _host_staged(t, group=None):
     """gloo has no device-side all-gather: collectives on CUDA tensors are staged through the host."""
     return t.is_cuda and dist.get_backend(group) == "gloo"

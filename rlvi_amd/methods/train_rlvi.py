@@ -50,9 +50,15 @@ def train_rlvi(train_loader, model, optimizer,
     every rank streams its own rows -- DDP's gradient averaging over equal shards turns the local
     1/B into the single-device 1/B_global --, the residuals of the rows each rank visited are
     exchanged once before the E-step, every rank runs the E-step / threshold on the identical
-    vector, and (train_acc, threshold) come back identical on every rank."""
+    vector, and (train_acc, threshold) come back identical on every rank.
+
+    Opt-in for loaders that give every rank the SAME samples every epoch
+    (rlvi_amd.dist.set_owner_sharding): nothing is exchanged or gathered at all -- the E-step and the
+    threshold run sharded over the ranks' own samples, the kernels passing their totals through the
+    peers' inboxes -- and only the owned entries of residuals / weights are kept up to date on a rank."""
     train_total = 0
-    ws = ops.workspace(weights.device, weights.shape[0], 0)
+    owner = rdist.owner_sharding() if rdist.world_size() > 1 else None
+    ws = owner[1] if owner is not None else ops.workspace(weights.device, weights.shape[0], 0)
     world = rdist.world_size()
     visited, sizes = [], []
 
@@ -64,7 +70,8 @@ def train_rlvi(train_loader, model, optimizer,
         logits = model(images)
         inv_scale = None                                       # 1 / B
         if world > 1:
-            visited.append(indexes)
+            if owner is None:
+                visited.append(indexes)
             sizes.append(int(labels.shape[0]))
             if rdist.ragged():                                 # unequal shards: world / B_global
                 inv_scale = world / rdist.global_batch(labels.shape[0])
@@ -85,10 +92,25 @@ def train_rlvi(train_loader, model, optimizer,
         if visited:
             rdist.exchange_residuals(residuals.detach(), torch.cat(visited))
 
-    # reference :99-103 plus the reduction of the accumulated top-1 percentages (:86-87,:105):
-    # E-step, optional truncation and the epoch scalars in one cooperative launch (+ threshold)
-    threshold, out = ops.epoch_end(residuals.detach(), weights, overfit=overfit,
-                                   threshold=threshold, batches=train_total, ws=ws)
+    if owner is not None:
+        # fixed ownership (rdist.set_owner_sharding): the same :99-103 on this rank's own samples, the
+        # kernels exchanging their per-node / per-bin totals through the peers' inboxes -- no gather
+        owned = owner[0]
+        r_own = residuals.detach()[owned].contiguous()
+        w_own = weights[owned].contiguous()
+        out = torch.empty(4, dtype=torch.float32, device=weights.device)
+        ops.estep_sharded(r_own, w_own, weights.shape[0], batches=train_total, out=out, ws=ws)
+        if overfit:
+            threshold, _, _ = ops.threshold_truncate_sharded(w_own, weights.shape[0], threshold, ws=ws)
+        residuals.detach()[owned] = r_own
+        weights[owned] = w_own
+        if not train_total:
+            out = None
+    else:
+        # reference :99-103 plus the reduction of the accumulated top-1 percentages (:86-87,:105):
+        # E-step, optional truncation and the epoch scalars in one cooperative launch (+ threshold)
+        threshold, out = ops.epoch_end(residuals.detach(), weights, overfit=overfit,
+                                       threshold=threshold, batches=train_total, ws=ws)
     if world > 1 and out is not None:
         rdist.mean_scalars(out[:2])                            # per-rank means over equal shards
 

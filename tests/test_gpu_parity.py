@@ -1251,6 +1251,125 @@ def test_sharded_estep_ranks_on_one_gpu(world, n_local, cap, gpu, oracle):
         assert np.array_equal(np.concatenate([results[r][2][i][7] for r in range(world)]), w_t)
 
 
+def _owner_data(N, D, C):
+    rng = np.random.default_rng(123)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    Wt = rng.standard_normal((D, C)).astype(np.float32)
+    y = np.argmax(X @ Wt, 1)
+    flip = rng.random(N) < 0.3                                  # 30 % symmetric label noise
+    y[flip] = rng.integers(0, C, int(flip.sum()))
+    return X, y.astype(np.int64)
+
+
+def _owner_batches(rank, world, N, per_rank, epoch):
+    owned = np.arange(rank, N, world)
+    order = np.random.default_rng(1000 * epoch + rank).permutation(owned)
+    return [order[s:s + per_rank] for s in range(0, len(order), per_rank)]
+
+
+def _owner_worker(rank, world, port, q, N, D, C, per_rank, epochs):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _sys.path.insert(0, _os.path.join(root, "tests"))
+    _os.environ["MASTER_ADDR"] = "127.0.0.1"
+    _os.environ["MASTER_PORT"] = str(port)
+    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch as _torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from rlvi_amd import _lib, ops as _ops
+        from rlvi_amd import dist as rdist
+        from rlvi_amd.methods import train_rlvi
+        import test_gpu_parity as T
+        _lib.check(_lib.load().rlvi_tune_set(b"RLVI_COOP_CAP", 100), "tune")   # two processes share the GPU
+        dev = _torch.device("cuda:0")
+        X, y = T._owner_data(N, D, C)
+        Xd, yd = _torch.from_numpy(X).to(dev), _torch.from_numpy(y).to(dev)
+        _torch.manual_seed(7)
+        model = DDP(_torch.nn.Linear(D, C).to(dev))
+        opt = _torch.optim.SGD(model.parameters(), lr=0.5)
+        residuals = _torch.zeros(N, device=dev)
+        weights = _torch.ones(N, device=dev)
+        ws = _ops.Workspace(dev, N, per_rank)
+        peers = rdist.setup_peers(ws)
+        owned = _torch.arange(rank, N, world, device=dev)
+        rdist.set_owner_sharding(owned, ws, peers)
+        thr, log = 0.0, []
+        for ep in range(epochs):
+            loader = [(Xd[ix], yd[ix], _torch.from_numpy(ix).to(dev)) for ix in T._owner_batches(rank, world, N, per_rank, ep)]
+            acc, thr = train_rlvi(loader, model, opt, residuals, weights, ep >= 1, thr)
+            log.append((acc, float(thr), weights[owned].cpu().numpy(), residuals[owned].cpu().numpy()))
+        params = _torch.cat([p.detach().flatten() for p in model.parameters()]).cpu().numpy()
+        rdist.set_owner_sharding(None, None, None)
+        dist.barrier()
+        peers.close()
+        q.put((rank, "ok", log, params))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + "\n" + traceback.format_exc(), None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_train_rlvi_owner_sharded_epoch_end_needs_no_collective(gpu):
+    """train_rlvi with fixed sample ownership (rlvi_amd.dist.set_owner_sharding): two processes on cuda:0
+    under DDP, each with its own half of the samples; the epoch end (E-step, then threshold + truncation
+    once `overfit`) runs sharded -- no residual exchange, no gather of pi.  Against ONE process running the
+    plain train_rlvi on the concatenated batches: the same pi on the owned samples, the same threshold,
+    train_acc and model after three epochs."""
+    import socket
+    import torch.multiprocessing as mp
+    torch, ops, dev = gpu
+    from rlvi_amd.methods import train_rlvi
+    N, D, C, per_rank, epochs, world = 16384, 32, 10, 2048, 3, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q, N, D, C, per_rank, epochs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in results), [r[1] for r in results]
+    # one process, the same global batches
+    X, y = _owner_data(N, D, C)
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    torch.manual_seed(7)
+    model = torch.nn.Linear(D, C).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    residuals, weights = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    thr = 0.0
+    for ep in range(epochs):
+        per = [_owner_batches(r, world, N, per_rank, ep) for r in range(world)]
+        loader = []
+        for b in range(len(per[0])):
+            ix = np.concatenate([per[r][b] for r in range(world)])
+            loader.append((Xd[ix], yd[ix], torch.from_numpy(ix).to(dev)))
+        acc, thr = train_rlvi(loader, model, opt, residuals, weights, ep >= 1, thr)
+        for r in range(world):
+            acc_r, thr_r, w_r, res_r = results[r][2][ep]
+            own = np.arange(r, N, world)
+            assert abs(acc_r - acc) <= 0.02, (ep, acc_r, acc)
+            assert abs(thr_r - float(thr)) <= 2e-4 * max(abs(float(thr)), 1e-3), (ep, thr_r, float(thr))
+            w1 = weights.cpu().numpy()[own]
+            trunc_differs = (w_r == 0) != (w1 == 0)            # (a weight within rounding of the threshold)
+            assert trunc_differs.mean() <= 1e-3
+            np.testing.assert_allclose(w_r[~trunc_differs], w1[~trunc_differs], rtol=2e-3, atol=2e-6)
+            np.testing.assert_allclose(res_r, residuals.cpu().numpy()[own], rtol=2e-3, atol=2e-5)
+    params = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu().numpy()
+    for r in range(world):
+        np.testing.assert_allclose(results[r][3], params, rtol=2e-3, atol=2e-5)
+
+
 def test_sharded_estep_refuses_a_workspace_without_a_peer_table(gpu):
     torch, ops, dev = gpu
     from rlvi_amd import _lib
