@@ -382,8 +382,8 @@ def main():
         extra["fused_em_us"] = fe_ms * 1e3
         extra["fused_em_iters"] = int(it_f.item())
         # (one launch, the block resident in LDS between the passes, when the shape allows: fused_em.hip;
-        #  bytes = logits in + gradient out + labels, pi in/out, loss rows)
-        extra["fused_em_frac"] = (B * (2 * C * 4 + 8 + 12) / (fe_ms * 1e-3)) / HBM_PEAK
+        #  V2 = 2*C*s + 16 bytes per sample -- logits in, gradient out, label, pi out, loss row out)
+        extra["fused_em_frac"] = (B * (2 * C * 4 + 16) / (fe_ms * 1e-3)) / HBM_PEAK
         from rlvi_amd import _lib as _l
         _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
         extra["fused_em_3launch_us"] = timed(fused_only, K, W, use_graph) / K * 1e3
