@@ -74,6 +74,19 @@ extern "C" int rlvi_peer_open(const void *handle64, void **inbox) {
     return 0;
 }
 
+// 1 if the current device can map memory of device `peer_device` (ordinals of THIS process), 0 if not,
+// negative on an error: asked before opening a handle that lives on another GPU.
+extern "C" int rlvi_peer_can_access(int peer_device) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return RLVI_E_WS;
+    if (peer_device == cur) return 1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || peer_device < 0 || peer_device >= n) return RLVI_E_SHAPE;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, cur, peer_device) != hipSuccess) return RLVI_E_WS;
+    return can ? 1 : 0;
+}
+
 extern "C" int rlvi_peer_close(void *inbox) {
     if (!inbox) return 0;
     return (int)hipIpcCloseMemHandle(inbox);

@@ -246,7 +246,7 @@ class Peers:
             self.own = own
             handle = ctypes.create_string_buffer(64)
             _lib.check(L.rlvi_peer_export(own, handle), "rlvi_peer_export")
-            raw = handle.raw
+            raw = (handle.raw, torch.cuda.current_device())
         except Exception as e:  # noqa: BLE001  (agreed on below: every rank raises or none)
             err = repr(e)
         handles = [raw]
@@ -260,8 +260,12 @@ class Peers:
                     if r == self.rank:
                         ptrs[r] = self.own.value
                     else:
+                        # (ordinals are comparable when every process sees all GPUs, as under torchrun;
+                        #  with one masked GPU per process they are all 0 and the open decides)
+                        if handles[r][1] != torch.cuda.current_device() and L.rlvi_peer_can_access(handles[r][1]) == 0:
+                            raise _lib.RlviError(f"GPU {torch.cuda.current_device()} cannot map the memory of GPU {handles[r][1]}")
                         p = ctypes.c_void_p()
-                        _lib.check(L.rlvi_peer_open(handles[r], ctypes.byref(p)), "rlvi_peer_open")
+                        _lib.check(L.rlvi_peer_open(handles[r][0], ctypes.byref(p)), "rlvi_peer_open")
                         self.mapped.append(p)
                         ptrs[r] = p.value
                 _lib.check(L.rlvi_workspace_set_peers(ws.ptr, self.rank, self.world, ptrs, ops._stream_ptr()),
