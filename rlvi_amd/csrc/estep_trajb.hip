@@ -50,7 +50,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     const int64_t hi = lo + L < N ? lo + L : N;
     // (sharded over several GPUs: N samples here, Nall over all ranks, pt the peers' inboxes;
     //  otherwise Nall == N and pt == nullptr)
-    const TbWarm wm = tb_warm(ws, Nall, K);
+    const TbWarm wm = tb_warm(ws, Nall, K, pt != nullptr);
 
     // ---- slice -> registers: raw residuals and the caller's pi
     float l[E], ev[E], q0[E];

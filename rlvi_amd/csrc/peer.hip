@@ -108,7 +108,10 @@ extern "C" int rlvi_workspace_set_peers(void *ws, int rank, int world, void *con
         t.inbox[r] = (unsigned long long)(uintptr_t)inboxes[r];
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemcpyAsync(static_cast<char *>(ws) + WS_PEER_OFF, &t, sizeof(t), hipMemcpyHostToDevice, st);
+    // the sharded solves start cold, and alike on every rank
+    hipError_t e = hipMemsetAsync(static_cast<char *>(ws) + WS_PEER_OFF, 0, WS_PEER_BYTES, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(static_cast<char *>(ws) + WS_PEER_OFF, &t, sizeof(t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int)e;

@@ -127,8 +127,14 @@ struct PeerTable {
     unsigned long long inbox[MAX_PEERS];        // device address of rank r's inbox; [rank] is the local one
 };
 constexpr size_t WS_PEER_OFF = WS_FEREC_OFF + WS_FEREC_BYTES;
-constexpr size_t WS_PEER_BYTES = 256;
-static_assert(sizeof(PeerTable) <= WS_PEER_BYTES, "peer table must fit its workspace region");
+// behind the table: the warm-start state of the SHARDED solves (the same layout as the region at
+// WS_TRAJ_OFF).  Only sharded calls touch it and rlvi_workspace_set_peers zeroes it, so it is identical on
+// every rank whatever else a rank did with its workspace -- the ranks must agree on how many nodes a
+// round evaluates and on the threshold's guesses.
+constexpr size_t WS_PEER_TABLE_BYTES = 256;
+constexpr size_t WS_PEER_STATE_OFF = WS_PEER_OFF + WS_PEER_TABLE_BYTES;
+constexpr size_t WS_PEER_BYTES = WS_PEER_TABLE_BYTES + WS_TRAJ_BYTES;
+static_assert(sizeof(PeerTable) <= WS_PEER_TABLE_BYTES, "peer table must fit its workspace region");
 // an inbox (uncached device memory that the peers map through an IPC handle and write over xGMI):
 // E-step part [2 parities][64 nodes][MAX_PEERS source ranks][8 self-tagged granules] = 64 KiB, then the
 // threshold part [2 parities][512 records][MAX_PEERS source ranks][4 granules] = 256 KiB

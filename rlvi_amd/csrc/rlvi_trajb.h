@@ -116,8 +116,9 @@ struct TbWarm {
     float rn_l;       // lane k: guessed node k
     int it;
 };
-__device__ __forceinline__ TbWarm tb_warm(void *ws, int64_t N, int K) {
-    const TrajState *state = reinterpret_cast<const TrajState *>(static_cast<char *>(ws) + WS_TRAJ_OFF);
+__device__ __forceinline__ TbWarm tb_warm(void *ws, int64_t N, int K, bool sharded = false) {
+    const TrajState *state = reinterpret_cast<const TrajState *>(static_cast<char *>(ws) +
+                                                                 (sharded ? WS_PEER_STATE_OFF : WS_TRAJ_OFF));
     const int lane = threadIdx.x & (WAVE - 1);
     TbWarm w;
     w.warm = state->n == (long long)N && state->k == K;
@@ -170,7 +171,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
     WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
     gu64 *bufA = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG3A_OFF));
     gu64 *bufB = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG3B_OFF));
-    TrajState *state = reinterpret_cast<TrajState *>(wsb + WS_TRAJ_OFF);
+    TrajState *state = reinterpret_cast<TrajState *>(wsb + (pt != nullptr ? WS_PEER_STATE_OFF : WS_TRAJ_OFF));
     uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
     // (sharded over several GPUs: a peer may legitimately be late -- another process, another stream --,

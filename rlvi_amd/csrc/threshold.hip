@@ -478,7 +478,7 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     WsHeader *hdr = reinterpret_cast<WsHeader *>(wsb);
     gu64 *bufA = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG4A_OFF));
     gu64 *bufB = (gu64 *)(reinterpret_cast<unsigned long long *>(wsb + WS_XCHG4B_OFF));
-    ThrState *state = reinterpret_cast<ThrState *>(wsb + WS_THRSTATE_OFF);
+    ThrState *state = reinterpret_cast<ThrState *>(wsb + (pt != nullptr ? WS_PEER_STATE_OFF + 384 : WS_THRSTATE_OFF));
     uint32_t tag = __hip_atomic_load((gu32 *)&hdr->epoch_base, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const unsigned long long spin_ticks = spin_bound(hdr) * (pt != nullptr ? 100ull : 1ull);

@@ -1167,10 +1167,18 @@ def _sharded_estep_worker(rank, world, port, q, n_local, cap):
             _lib.check(_lib.load().rlvi_tune_set(b"RLVI_COOP_CAP", cap), "tune")
         dev = _torch.device("cuda:0")
         N = n_local * world
-        ws = _ops.Workspace(dev, n_local, 0)
+        ws = _ops.Workspace(dev, n_local * world, 0)
         peers = rdist.setup_peers(ws)
         out = []
         lo, hi = rank * n_local, (rank + 1) * n_local
+        if rank == 0:
+            # one rank alone does something else with its workspace (an E-step and a threshold over N values):
+            # the sharded calls keep their own warm-start state, so the ranks still agree
+            rx = _torch.from_numpy(_synth.residual_vector("exp", N, seed=9)).to(dev)
+            wx = _torch.ones(N, device=dev)
+            _ops.estep_deep(rx, wx, ws=ws)
+            _ops.threshold_truncate(wx, 0.0, ws=ws)
+            _torch.cuda.synchronize()
         for (kind, seed) in (("bimodal", 1), ("bimodal", 1), ("exp", 2), ("heavy", 3), ("bimodal", 4)):
             r_all = _synth.residual_vector(kind, N, seed=seed)
             w_all = np.random.default_rng(seed).random(N).astype(np.float32)
