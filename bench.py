@@ -370,6 +370,11 @@ def main():
                        "rlvi_threshold_truncate_f32")
         extra["threshold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
         extra["threshold_n"] = N
+        # (the same vector every call: every guess from the previous call is right.  Without any guess:)
+        from rlvi_amd import _lib as _lt
+        _lt.check(_lt.load().rlvi_tune_set(b"RLVI_THR_WARM", 0), "tune")
+        extra["threshold_cold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
+        _lt.check(_lt.load().rlvi_tune_set(b"RLVI_THR_WARM", 1), "tune")
         # in-batch E+M (V2): NLL pass -> E-step on this batch -> weighted loss + gradient
         pi_b = torch.ones(B, dtype=torch.float32, device=dev)
         rows_b = torch.empty(B, dtype=torch.float32, device=dev)
