@@ -96,6 +96,10 @@ def train_rlvi(train_loader, model, optimizer,
         # fixed ownership (rdist.set_owner_sharding): the same :99-103 on this rank's own samples, the
         # kernels exchanging their per-node / per-bin totals through the peers' inboxes -- no gather
         owned = owner[0]
+        # (the kernels below wait for the other ranks' kernels, bounded at 100 x the spin bound: line the
+        #  ranks up on the host first, so that a rank that is seconds behind -- I/O, an evaluation pass --
+        #  is waited for here and not inside a spinning kernel)
+        torch.distributed.barrier()
         r_own = residuals.detach()[owned].contiguous()
         w_own = weights[owned].contiguous()
         out = torch.empty(4, dtype=torch.float32, device=weights.device)
