@@ -324,6 +324,16 @@ def main():
     launch_mode = {}
     K, W = a.steps, a.warmup
     ms_total = timed(step, K, W, use_graph)
+    if estep_mode[0] == "sharded":
+        # a timed region that left a device status behind on any rank (a wait on a peer gave up) is not a
+        # measurement: every rank goes back to the replicated E-step and the region is timed again
+        clean, why = agree(ws.status() == 0, f"device status {ws.status()}")
+        if not clean:
+            ws.clear_status()
+            estep_mode[0] = "replicated"
+            estep_note = f"sharded step left a device status behind ({why}); re-timed replicated"
+            use_graph = (not a.no_graph) and a.dist_graph == "auto"
+            ms_total = timed(step, K, W, use_graph)
     ms_step = ms_total / K
     value = (B * world) / (ms_step * 1e-3)
 
