@@ -62,6 +62,14 @@ def set_owner_sharding(owned, ws, peers):
     the call only the OWNED entries of residuals / weights are meaningful on a rank.  `ws`: the workspace
     `peers = setup_peers(ws)` was set up on.  None switches back to the replicated form."""
     global _OWNER
+    if owned is not None and is_dist():
+        # a collective: the sharded kernels take 4096 .. 2 097 152 samples per rank, and a rank that cannot
+        # launch would leave the others waiting for it -- so every rank learns every rank's share now
+        from ._lib import RlviError
+        sizes = [None] * dist.get_world_size()
+        dist.all_gather_object(sizes, int(owned.numel()))
+        if min(sizes) < 4096 or max(sizes) > 2097152:
+            raise RlviError(f"owner sharding needs 4096 .. 2097152 samples on every rank, got {sizes}")
     _OWNER = None if owned is None else (owned, ws, peers)
 
 
