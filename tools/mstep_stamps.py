@@ -32,6 +32,10 @@ torch.cuda.synchronize()
 off = ops.debug_scratch_offset()
 raw = ws.buf[off:off + 4096 * 128].cpu().numpy().view(np.uint64).reshape(-1, 16).astype(np.int64)
 raw = raw[raw[:, 0] > 0]
+if len(raw) == 0:
+    sys.exit("no stamps in the workspace: this library was not built with -DRLVI_MSTEP_STAMPS\n"
+             "  python tools/build_variants.py stamps=-DRLVI_MSTEP_STAMPS\n"
+             "  RLVI_LIB_PATH=rlvi_amd/librlvi_stamps.so python tools/mstep_stamps.py")
 t0 = raw[:, 0].min()
 names = ["start", "dma issued", "tile landed", "row max", "row sum", "arith done", "stores issued", "stores retired"]
 print(f"{len(raw)} waves; us since first wave start (min / p10 / median / p90 / max)")
