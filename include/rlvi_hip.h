@@ -146,6 +146,7 @@ int rlvi_peer_open(const void *handle64, void **inbox);
 int rlvi_peer_close(void *inbox);
 int rlvi_peer_can_access(int peer_device);   /* 1 / 0: the current device can map `peer_device`'s memory */
 int rlvi_workspace_set_peers(void *ws, int rank, int world, void *const *inboxes, void *stream);
+int rlvi_workspace_clear_peers(void *ws, void *stream);   /* before closing / freeing the inboxes */
 int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t n_local, int64_t n_all,
                            float tol, int maxiter, int64_t batches, float *out, int32_t *out_iters,
                            void *ws, void *stream);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "rlvi_peer_open": (_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
     "rlvi_peer_close": (_int, [_vp]),
     "rlvi_peer_can_access": (_int, [_int]),
+    "rlvi_workspace_clear_peers": (_int, [_vp, _vp]),
     "rlvi_workspace_set_peers": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_void_p), _vp]),
     "rlvi_threshold_truncate_sharded_f32": (_int, [_vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "rlvi_estep_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _f32, _int, _i64, _vp, _vp, _vp, _vp]),

@@ -119,3 +119,15 @@ extern "C" int rlvi_workspace_set_peers(void *ws, int rank, int world, void *con
     g_world[ws] = world;
     return 0;
 }
+
+// Forget the peer table of a workspace (before the inboxes it points at are unmapped / freed): sharded calls
+// on it return RLVI_E_WS from then on instead of launching on stale addresses.
+extern "C" int rlvi_workspace_clear_peers(void *ws, void *stream) {
+    if (!ws) return RLVI_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(static_cast<char *>(ws) + WS_PEER_OFF, 0, WS_PEER_BYTES, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(st);
+    peers_forget(ws);
+    return (int)e;
+}

@@ -245,6 +245,7 @@ class Peers:
         self.world = dist.get_world_size(group) if multi else 1
         self.rank = dist.get_rank(group) if multi else 0
         self.own, self.mapped = None, []
+        self._ws = ws
         err, raw = None, None
         try:
             if self.world > 8:
@@ -292,6 +293,14 @@ class Peers:
             raise _lib.RlviError("peer set-up failed: " + "; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e))
 
     def close(self):
+        ws = getattr(self, "_ws", None)
+        if ws is not None and getattr(ws, "ptr", None) is not None and (self.mapped or self.own is not None):
+            try:        # sharded calls on this workspace are refused from now on (no stale addresses)
+                from . import ops
+                self._L.rlvi_workspace_clear_peers(ws.ptr, ops._stream_ptr())
+            except Exception:  # noqa: BLE001  (tearing down: nothing to report to)
+                pass
+        self._ws = None
         for p in self.mapped:
             self._L.rlvi_peer_close(p)
         self.mapped = []

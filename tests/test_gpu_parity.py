@@ -1408,6 +1408,10 @@ def test_sharded_estep_one_rank_is_the_plain_estep(gpu):
             assert ws_a.status() == 0
     finally:
         peers.close()
+    # after close() the workspace has no peer table any more: refused, not launched on stale addresses
+    from rlvi_amd import _lib
+    with pytest.raises(_lib.RlviError):
+        ops.estep_sharded(torch.rand(N, device=dev), torch.ones(N, device=dev), N, ws=ws_a)
 
 
 @pytest.mark.parametrize("key", ["C10", "C100", "C101"])
