@@ -117,20 +117,23 @@ namespace rlvi {
 // the results of a lane are D[row = (l>>4) + 4 r][col = l&15], all columns alike.  Lanes with
 // (l&15) < 4 return the dot product of row (l>>4) + 4 (l&15) (`mine` tells which), the others 0.
 typedef double aux_d4_t __attribute__((ext_vector_type(4)));
+// [kbeg, kend): the columns this call covers (kbeg a multiple of 4; the whole row by default).
 __device__ __forceinline__ double rows16_dot_mfma(const double *__restrict__ X, const double *__restrict__ v,
-                                                  int64_t row0, int64_t n, int64_t d, int &myrow) {
+                                                  int64_t row0, int64_t n, int64_t d, int &myrow,
+                                                  int64_t kbeg = 0, int64_t kend = -1) {
+    if (kend < 0) kend = d;
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kk = lane >> 4;
     const int64_t row = row0 + i;
     aux_d4_t acc = {0.0, 0.0, 0.0, 0.0};
     const bool rok = row < n;
     const double *xr = X + (rok ? row : 0) * d;
-    int64_t k0 = 0;
+    int64_t k0 = kbeg;
     // four k-panels per trip, their eight loads in flight together (a plain loop waits for one 8-byte load per
     // matrix instruction: 40 -> 17 us for 256 x 561, 12 -> 4.5 us for 256 x 60; eight per trip: no further
     // gain); the accumulation order is the plain loop's: the same bits
     constexpr int XU = 4;
-    for (; k0 + 4 * XU <= d; k0 += 4 * XU) {
+    for (; k0 + 4 * XU <= kend; k0 += 4 * XU) {
         double a[XU], b[XU];
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
@@ -141,10 +144,10 @@ __device__ __forceinline__ double rows16_dot_mfma(const double *__restrict__ X, 
 #pragma unroll
         for (int u = 0; u < XU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
     }
-    for (; k0 < d; k0 += 4) {
+    for (; k0 < kend; k0 += 4) {
         const int64_t k = k0 + kk;
-        const double a = (rok && k < d) ? xr[k] : 0.0;
-        const double b = k < d ? v[k] : 0.0;
+        const double a = (rok && k < kend) ? xr[k] : 0.0;
+        const double b = k < kend ? v[k] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     myrow = i < 4 ? kk + 4 * i : -1;
@@ -211,13 +214,18 @@ __global__ __launch_bounds__(256) void linreg_scale_kernel(double *__restrict__ 
         losses[i] = 0.5 * losses[i] / sigma2;
 }
 
+// -log sigmoid(p) without overflow (online-learning/main.py:295-296 with :84-85 folded in)
+__device__ __forceinline__ double logistic_nll_of(double p) {
+    return p >= 0.0 ? log1p(exp(-p)) : -p + log1p(exp(p));
+}
+
 template <bool MFMA>
 __global__ __launch_bounds__(256) void logistic_nll_kernel(const double *__restrict__ X,
                                                            const double *__restrict__ wv, double b,
                                                            int64_t n, int64_t d,
                                                            double *__restrict__ losses) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto nll = [](double p) { return p >= 0.0 ? log1p(exp(-p)) : -p + log1p(exp(p)); };
+    auto nll = [](double p) { return logistic_nll_of(p); };
     if (MFMA) {
         for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16; r0 < n; r0 += (int64_t)gridDim.x * 64) {
             int myrow;
@@ -231,6 +239,31 @@ __global__ __launch_bounds__(256) void logistic_nll_kernel(const double *__restr
             p = wave_sum(p) + b;
             if (lane == 0) losses[i] = nll(p);
         }
+    }
+}
+
+// Long rows (d >= 128, e.g. the 561 HAR features of online-learning): one workgroup per 16-row block, its
+// four waves a quarter of the columns each, the four partial dot products added in wave order -- a quarter of
+// the dependent load round trips per wave (256 x 561: 17 -> 6 us).
+__global__ __launch_bounds__(256) void logistic_nll_splitk_kernel(const double *__restrict__ X,
+                                                                  const double *__restrict__ wv, double b,
+                                                                  int64_t n, int64_t d,
+                                                                  double *__restrict__ losses) {
+    __shared__ double part[4][16];
+    const int wave = threadIdx.x >> 6;
+    const int64_t dq = ((d + 15) / 16) * 4;                 // columns per wave, a multiple of 4
+    const int64_t kbeg = wave * dq, kend = kbeg + dq < d ? kbeg + dq : d;
+    for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < n; r0 += (int64_t)gridDim.x * 16) {
+        int myrow;
+        const double p = kbeg < d ? rows16_dot_mfma(X, wv, r0, n, d, myrow, kbeg, kend) : 0.0;
+        if (kbeg >= d) { const int lane = threadIdx.x & 63; myrow = (lane & 15) < 4 ? (lane >> 4) + 4 * (lane & 15) : -1; }
+        if (myrow >= 0) part[wave][myrow] = p;
+        __syncthreads();
+        if (threadIdx.x < 16 && r0 + threadIdx.x < n) {
+            const double t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+            losses[r0 + threadIdx.x] = logistic_nll_of(t + b);
+        }
+        __syncthreads();
     }
 }
 
@@ -264,6 +297,11 @@ extern "C" int rlvi_logistic_nll_f64(const double *X, const double *w, double b,
     int nb = (int)(mfma ? (n + 63) / 64 : (n + 3) / 4);
     if (nb > 1024) nb = 1024;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mfma && d >= 128) {
+        int nbk = (int)((n + 15) / 16);
+        if (nbk > 4096) nbk = 4096;
+        return launch(logistic_nll_splitk_kernel, dim3(nbk), dim3(256), 0, st, X, w, b, n, d, losses);
+    }
     return mfma ? launch(logistic_nll_kernel<true>, dim3(nb), dim3(256), 0, st, X, w, b, n, d, losses)
                 : launch(logistic_nll_kernel<false>, dim3(nb), dim3(256), 0, st, X, w, b, n, d, losses);
 }
