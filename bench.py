@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- RLVI samples/sec (fused E+M step) on synthetic logits 65 536 x 100 per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+                                                           (is one of torchrun's N ranks)
 
 One "step" = one pass of the hot path over one batch, with BOTH halves inside the timed region:
   M  rlvi_mstep_fwd_bwd_f32   per-sample NLL, top-1, residual scatter, lagged-pi gather,
@@ -66,7 +67,80 @@ def parse():
                     help="debug: run the residual exchange (and its process group) at world size 1")
     ap.add_argument("--profile-only", action="store_true",
                     help="warmup + timed steps only (for rocprofv3 runs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="world > 1: weak = --rows rows on EVERY rank (N = rows x world samples); strong = --rows "
+                         "rows in all, rows / world on every rank (N = rows samples)")
+    ap.add_argument("--debug-absent-peer", type=int, default=-1,
+                    help="test hook: this rank never joins the start-up self-check of the sharded E-step, so "
+                         "the others' waits run into their bound and every rank lands on the replicated path")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def plan_ranks(requested, visible, same_device):
+    """(ranks to start, `not_measured` note or None) for `--gpus requested` on a box with `visible` devices."""
+    if same_device or visible >= requested:
+        return requested, None
+    return max(visible, 0), f"{requested} requested, {visible} visible"
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: become N ranks.  The parent makes NO GPU call (it only
+    counts devices, which does not initialise the runtime) and never replaces itself: it starts N fresh
+    children -- one per GPU, rendezvous on 127.0.0.1 --, passes rank 0's stdout (the one JSON line) through,
+    waits for all of them and exits non-zero if any child does.  Fewer visible devices than asked for (and
+    no --same-device): the run is made on the visible ones and says so in the record
+    ("not_measured": "N requested, M visible") instead of dressing an M-GPU number as an N-GPU one."""
+    import subprocess
+    import torch
+    visible = torch.cuda.device_count()
+    env = dict(os.environ)
+    n, note = plan_ranks(a.gpus, visible, a.same_device)
+    if note is not None:
+        print(f"# bench: {note}", file=sys.stderr)
+        if n < 1:
+            print(json.dumps({"metric": "RLVI samples/sec (fused E+M step)", "value": None, "unit": "samples/s",
+                              "n_gpus": 0, "not_measured": note}))
+            return 3
+        env["RLVI_BENCH_REQUESTED_GPUS"] = str(a.gpus)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n),
+               LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    # wait for all; a rank that fails takes the others with it after a grace period (they would wait in
+    # a collective for ever): the exact children, by pid
+    rc, t_fail = 0, None
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is not None:
+                live.remove(p)
+                if c != 0 and rc == 0:
+                    rc, t_fail = c, time.time()
+        if t_fail is not None and live and time.time() - t_fail > 30.0:
+            for p in live:
+                p.terminate()
+            time.sleep(5.0)
+            for p in live:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    return rc
+
 
 
 def make_inputs(torch, dev, B, C, N, rank):
@@ -95,6 +169,11 @@ def make_inputs(torch, dev, B, C, N, rank):
 
 def main():
     a = parse()
+    # IPC handles of device memory (the peers' inboxes of the sharded E-step, RCCL's own buffers) need the
+    # dmabuf IPC mode on this driver stack; it has to be in the environment before the runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -106,6 +185,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.same_device:
         local = 0
+    not_measured = None
+    if "RLVI_BENCH_REQUESTED_GPUS" in os.environ:
+        not_measured = f"{os.environ['RLVI_BENCH_REQUESTED_GPUS']} requested, {world} visible"
+    elif not a.same_device and torch.cuda.device_count() < world:
+        # a launcher made more ranks than there are devices: nothing honest can be measured
+        if rank == 0:
+            print(json.dumps({"metric": "RLVI samples/sec (fused E+M step)", "value": None, "unit": "samples/s",
+                              "n_gpus": torch.cuda.device_count(),
+                              "not_measured": f"{world} ranks launched, {torch.cuda.device_count()} devices visible"}))
+        sys.exit(3)
     use_dist = world > 1 or a.force_collective
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -130,12 +219,20 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+        # ranks that drive the same GPU (--same-device) split its co-residency between them
+        rdist.declare_device_sharing()
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
-    if a.gpus != world and rank == 0:
+    if a.gpus != world and rank == 0 and not_measured is None:
         print(f"# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    B, C = a.rows, a.classes
+    C = a.classes
+    if a.scaling == "strong" and world > 1:
+        if a.rows % (16 * world):
+            raise SystemExit(f"--scaling strong: --rows {a.rows} must be a multiple of 16 x {world} ranks")
+        B = a.rows // world                  # the same global batch, split over the ranks
+    else:
+        B = a.rows
     N = B * world
     inv_scale = 1.0 / N                      # global 1/B: per-rank losses / grads SUM to 1 device
     d0, labels, idx_local, logits, grads, weights, residuals = make_inputs(torch, dev, B, C, N, rank)
@@ -174,6 +271,8 @@ def main():
 
     estep_mode = ["replicated" if use_dist else "single"]
     estep_note = ""
+    status_log = []        # every non-zero device status seen after a leg: it stays in the JSON line
+    last_status = [0]
     lo_own, hi_own = rank * B, (rank + 1) * B
     peers_keep = []
 
@@ -196,12 +295,21 @@ def main():
             peers_keep.append(rdist.setup_peers(ws))
         except Exception as e:                               # noqa: BLE001 (Peers agreed on it: all ranks)
             return "replicated", f"sharded unavailable ({e})"
+        # every rank asks the library whether its sharded launch would be admitted (shape, co-residency
+        # this process is entitled to) BEFORE anybody launches: a rank that cannot would leave the others
+        # waiting for its records
+        from rlvi_amd import _lib as _lc
+        can, why = agree(_lc.load().rlvi_estep_sharded_check(B, N, 40, 1) == 0,
+                         f"rlvi_estep_sharded_check({B}, {N}) refused")
+        if not can:
+            return "replicated", f"sharded not launchable ({why})"
         try:
             full = synth.residual_vector("bimodal", N, seed=5)
             r_s = torch.from_numpy(full[lo_own:hi_own].copy()).to(dev)
             w_s = torch.ones(B, dtype=torch.float32, device=dev)
             it_s = torch.zeros(1, dtype=torch.int32, device=dev)
-            ops.estep_sharded(r_s, w_s, N, iters=it_s, ws=ws)
+            if rank != a.debug_absent_peer:
+                ops.estep_sharded(r_s, w_s, N, iters=it_s, ws=ws)
             ws2 = ops.Workspace(dev, N, 0)
             r_f = torch.from_numpy(full).to(dev)
             w_f = torch.ones(N, dtype=torch.float32, device=dev)
@@ -218,6 +326,8 @@ def main():
         ok, why = agree(ok, note)
         if ok:
             return "sharded", ""
+        if ws.status():
+            status_log.append({"leg": "sharded self-check", "status": ws.status()})
         ws.clear_status()
         if a.estep_dist == "sharded" and rank == 0:
             print(f"# --estep-dist sharded refused: {why}", file=sys.stderr)
@@ -234,8 +344,11 @@ def main():
     with torch.cuda.stream(side):
         ws = ops.Workspace(dev, N, B)
         torch.cuda.synchronize()
+        setup_s = None
         if use_dist and a.estep_dist != "replicated":
+            t_setup = time.perf_counter()
             estep_mode[0], estep_note = choose_estep_mode(ws)
+            setup_s = time.perf_counter() - t_setup     # peers' set-up + self-check (bounded: see DESIGN 6)
         step(0, ws)
         torch.cuda.synchronize()
         it_gpu = int(iters.item())
@@ -316,6 +429,13 @@ def main():
             t = torch.tensor([ms], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t.item())
+        # a device-side condition raised inside this leg (a wait that hit its bound, a row out of range) is
+        # attributed to it, kept for the JSON line and cleared so that the next leg starts clean
+        last_status[0] = ws.status()
+        if last_status[0]:
+            status_log.append({"leg": fn.__name__, "rank": rank, "status": last_status[0],
+                               "estep_dist": estep_mode[0]})
+            ws.clear_status()
         return ms
 
     # world > 1: the RCCL all-gather is captured too when RCCL allows it (--dist-graph auto)
@@ -327,9 +447,11 @@ def main():
     if estep_mode[0] == "sharded":
         # a timed region that left a device status behind on any rank (a wait on a peer gave up) is not a
         # measurement: every rank goes back to the replicated E-step and the region is timed again
-        clean, why = agree(ws.status() == 0, f"device status {ws.status()}")
+        clean, why = agree(last_status[0] == 0, f"device status {last_status[0]}")
         if not clean:
-            ws.clear_status()
+            if not status_log or status_log[-1].get("leg") != "step":
+                status_log.append({"leg": "step", "rank": rank, "status": 0, "estep_dist": "sharded",
+                                   "other_ranks": why})
             estep_mode[0] = "replicated"
             estep_note = f"sharded step left a device status behind ({why}); re-timed replicated"
             use_graph = (not a.no_graph) and a.dist_graph == "auto"
@@ -340,7 +462,8 @@ def main():
     result = {
         "metric": "RLVI samples/sec (fused E+M step)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": a.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic logits {B}x{C} per GPU, N={N} samples, "
                                "M-step (lagged pi) + E-step every step, HBM-cold rotation of "
@@ -351,8 +474,11 @@ def main():
                                 "; residuals all-gathered, E-step replicated on every rank"),
                    "rows_per_gpu": B, "classes": C, "n_samples": N,
                    "launch": launch_mode.get("step", "eager"), "estep_dist": estep_mode[0],
-                   **({"estep_dist_note": estep_note} if estep_note else {})},
+                   **({"estep_dist_note": estep_note} if estep_note else {}),
+                   **({"estep_dist_setup_s": round(setup_s, 3)} if setup_s is not None else {})},
     }
+    if not_measured is not None:
+        result["not_measured"] = not_measured
     if a.profile_only:
         if rank == 0:
             print(json.dumps(result))
@@ -451,7 +577,11 @@ def main():
     result["parts"].update(extra)
     result["parity"] = parity
     st = ws.status()
-    result["device_status"] = st
+    for ev in status_log:
+        st |= int(ev["status"])
+    result["device_status"] = st          # OR over every leg of this run (0 = no device-side condition anywhere)
+    if status_log:
+        result["device_status_events"] = status_log
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

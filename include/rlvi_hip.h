@@ -24,6 +24,10 @@
  *   - kernels whose workgroups wait for each other (E-step, threshold) size their grid from the
  *     occupancy query of the current device, so that all of them are resident at once; every wait
  *     is bounded in wall time (RLVI_SPIN_BOUND_MS, default 100) and sets RLVI_ST_TIMEOUT.
+ *     The query sees THIS process only: when S processes drive the same GPU, tell each of them
+ *     (rlvi_tune_set("RLVI_DEVICE_SHARERS", S), or the environment variable of that name) and every
+ *     process takes 1/S of the proven capacity; rlvi_amd.dist does it for the ranks of a process
+ *     group by comparing rlvi_device_pci_bus_id() over the ranks.
  */
 #ifndef RLVI_HIP_H
 #define RLVI_HIP_H
@@ -35,7 +39,8 @@
 extern "C" {
 #endif
 
-#define RLVI_ABI_VERSION 1
+#define RLVI_ABI_VERSION 2   /* 2: workspace layout of round 2 (peer table, sharded state), rlvi_device_pci_bus_id,
+                                 rlvi_estep_sharded_check; set_peers zeroes the local inbox */
 
 #define RLVI_E_NULL   (-1) /* required pointer is NULL                 */
 #define RLVI_E_SHAPE  (-2) /* negative / inconsistent size             */
@@ -60,6 +65,9 @@ const char *rlvi_error_string(int code);
 int rlvi_tune_set(const char *name, int value);
 /* Compute units of the current device as the launchers see them. */
 int rlvi_device_cus(void);
+/* PCI bus id ("0000:c1:00.0") of the current device into buf[len >= 16]: the identity of the physical GPU,
+ * the same in every process whatever the visible-device masks made of the ordinals. */
+int rlvi_device_pci_bus_id(char *buf, int len);
 
 /* Bytes of workspace needed for vectors up to max_n samples and batches up to max_b rows. */
 size_t rlvi_workspace_bytes(int64_t max_n, int64_t max_b);
@@ -130,7 +138,16 @@ int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol, 
  *   rlvi_peer_alloc / _export / _open / _close / _free   one 320-KiB inbox per rank in uncached device
  *       memory, exchanged as 64-byte IPC handles by the host program (rlvi_amd.dist.setup_peers)
  *   rlvi_workspace_set_peers(ws, rank, world, inboxes, stream)   inboxes[r] = rank r's inbox as mapped
- *       in this process; call at the same program point on every rank (resets the round counter)
+ *       in this process; call at the same program point on every rank: it resets the round counter and
+ *       the sharded warm-start state and ZEROES THE LOCAL INBOX (records of an earlier set-up must not
+ *       match the new rounds' tags), so a host-side barrier over the ranks must separate it from the
+ *       first sharded call (a peer must not push before this rank's inbox is clean).  After a sharded
+ *       call raised RLVI_ST_TIMEOUT the ranks' round counters may differ: set the peers up again (on
+ *       every rank) before the next sharded call.
+ *   rlvi_estep_sharded_check(n_local, n_all, maxiter, with_out)   0 if rlvi_estep_sharded_f32 would launch
+ *       for this shape on this device now, RLVI_E_LIMIT if not; nothing is launched.  The ranks compare
+ *       answers before the first collective call.  The sharded solve uses the 256-thread geometry on
+ *       every rank (shards may differ in length; the exchanged record layout may not).
  *   rlvi_estep_sharded_f32   a collective: every rank calls it the same number of times; returns
  *       RLVI_E_LIMIT when the shape is outside the trajectory kernel (n_local < 4096, ...).
  *       out != NULL: this rank's M-step scalars of the epoch too (as rlvi_epoch_end_f32, x 1/batches).
@@ -147,6 +164,7 @@ int rlvi_peer_close(void *inbox);
 int rlvi_peer_can_access(int peer_device);   /* 1 / 0: the current device can map `peer_device`'s memory */
 int rlvi_workspace_set_peers(void *ws, int rank, int world, void *const *inboxes, void *stream);
 int rlvi_workspace_clear_peers(void *ws, void *stream);   /* before closing / freeing the inboxes */
+int rlvi_estep_sharded_check(int64_t n_local, int64_t n_all, int maxiter, int with_out);
 int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t n_local, int64_t n_all,
                            float tol, int maxiter, int64_t batches, float *out, int32_t *out_iters,
                            void *ws, void *stream);
@@ -173,7 +191,8 @@ int rlvi_epoch_end_f32(float *residuals, float *weights, int64_t N, float tol, i
 /* ---------------------------------------------------------------------------------------
  * Type-II-error threshold, replaces false_negative_criterion(weights, alpha),
  * train_rlvi.py:41-49 (sum, sort, cumsum, count, gather) without sorting: the position is
- * found by bisection on the order-preserving key with exact prefix sums.
+ * found by a radix descent (8 bits per digit, most significant first) on the order-preserving key
+ * with exact integer per-bin counts and sums.
  *   thr_out  device fp32: the threshold
  * rlvi_threshold_truncate_f32 additionally applies train_rlvi.py:102-103:
  *   *thr_inout = max(*thr_inout, criterion); weights[weights < *thr_inout] = 0

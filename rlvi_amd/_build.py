@@ -47,6 +47,10 @@ def build(force=False, verbose=False, extra_flags=None, lib=LIB):
         if force or _newer(obj, [src] + hdrs):
             jobs.append([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj])
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in sources()]
+    # an object whose source is gone (a kernel file that was removed or renamed) must not linger
+    for old in glob.glob(os.path.join(objdir, "*.o")):
+        if old not in objs:
+            os.remove(old)
 
     def run(cmd):
         if verbose:

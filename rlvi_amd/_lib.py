@@ -22,6 +22,7 @@ SIGNATURES = {
     "rlvi_error_string": (ctypes.c_char_p, [_int]),
     "rlvi_tune_set": (_int, [ctypes.c_char_p, _int]),
     "rlvi_device_cus": (_int, []),
+    "rlvi_device_pci_bus_id": (_int, [ctypes.c_char_p, _int]),
     "rlvi_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "rlvi_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
     "rlvi_workspace_status": (_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "rlvi_workspace_clear_peers": (_int, [_vp, _vp]),
     "rlvi_workspace_set_peers": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_void_p), _vp]),
     "rlvi_threshold_truncate_sharded_f32": (_int, [_vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "rlvi_estep_sharded_check": (_int, [_i64, _i64, _int, _int]),
     "rlvi_estep_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _f32, _int, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_mstep_fwd_bwd_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                       _vp, _i64, _vp, _vp, _vp]),
@@ -59,6 +61,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2          # RLVI_ABI_VERSION of include/rlvi_hip.h
 
 
 class RlviError(RuntimeError):
@@ -97,7 +100,7 @@ def load():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if L.rlvi_abi_version() != 1:
+    if L.rlvi_abi_version() != ABI_VERSION:
         raise RlviError("librlvi_gfx950.so ABI version mismatch")
     _lib = L
     return L

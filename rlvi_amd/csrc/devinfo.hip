@@ -113,6 +113,14 @@ int coop_cap_cached(const void *kernel, int block_threads, size_t dyn_lds) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_ncaps < MAX_CAPS) g_caps[g_ncaps++] = CapEntry{kernel, dev, block_threads, dyn_lds, cap};
     }
+    // Several PROCESSES on this device (rlvi_amd.dist.declare_device_sharing finds them by PCI bus id, or
+    // the environment says so): the occupancy query above sees one process's kernels only, so S processes
+    // that each size a cooperating grid from it can together ask for more workgroups than the device holds
+    // -- each grid then waits for slots the other one occupies until the spin bound ends both (the
+    // RLVI_ST_TIMEOUT recorded in round 2: two ranks on one GPU, each with 256 workgroups of a kernel the
+    // device admits two of per CU).  Every process takes 1/S of the proven capacity instead.
+    const int sharers = tune_get("RLVI_DEVICE_SHARERS", 1);
+    if (sharers > 1) cap /= sharers;
     return (forced > 0 && forced < cap) ? forced : cap;
 }
 
@@ -130,3 +138,15 @@ extern "C" int rlvi_tune_set(const char *name, int value) {
 }
 
 extern "C" int rlvi_device_cus(void) { return rlvi::device_info().cus; }
+
+// "0000:c1:00.0"-style PCI bus id of the current device: the same physical GPU has the same id in every
+// process of the node whatever HIP_VISIBLE_DEVICES made of the ordinals, so ranks that compare ids know
+// whether they share a device (rlvi_amd.dist.declare_device_sharing -> RLVI_DEVICE_SHARERS).
+extern "C" int rlvi_device_pci_bus_id(char *buf, int len) {
+    if (!buf) return RLVI_E_NULL;
+    if (len < 16) return RLVI_E_SHAPE;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipDeviceGetPCIBusId(buf, len, dev);
+}

@@ -22,7 +22,7 @@ enum { VAR_DEEP = 0, VAR_STD = 1, VAR_ONLINE = 2 };
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
                            float *mstep_out, double mstep_scale, int *rc, int64_t n_all = 0,
-                           int sharded = 0);
+                           int sharded = 0, int dry_run = 0);
 int peers_world_of(const void *ws);     // peer.hip: 0 = rlvi_workspace_set_peers never ran on it
 
 // t/(1+t) etc.: fp32 uses v_rcp_f32 (1 ulp) + multiply instead of the ~15-instruction IEEE
@@ -257,6 +257,20 @@ extern "C" int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t 
                                static_cast<hipStream_t>(stream), out, batches > 0 ? 1.0 / (double)batches : 1.0,
                                &rc, n_all, 1))
         return rc;
+    return RLVI_E_LIMIT;
+}
+
+// Would rlvi_estep_sharded_f32 launch for this shape on this device, now (with the co-residency this
+// process is entitled to)?  0 = yes, RLVI_E_LIMIT = no.  Nothing is launched (occupancy queries only): every rank asks
+// before the first collective call and the ranks compare answers (rlvi_amd.dist.set_owner_sharding,
+// bench.py), so that nobody starts a solve a peer cannot join.
+extern "C" int rlvi_estep_sharded_check(int64_t n_local, int64_t n_all, int maxiter, int with_out) {
+    if (n_local <= 0 || n_all < n_local || maxiter < 0) return RLVI_E_SHAPE;
+    int rc = 0;
+    float dummy_out = 0.0f;
+    if (try_launch_estep_trajb(nullptr, nullptr, n_local, 1e-3f, maxiter, nullptr, nullptr, nullptr, nullptr,
+                               with_out ? &dummy_out : nullptr, 1.0, &rc, n_all, 1, 1))
+        return 0;
     return RLVI_E_LIMIT;
 }
 

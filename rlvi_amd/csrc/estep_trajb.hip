@@ -34,7 +34,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
     float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G,
-    int64_t Nall, PeerTable *__restrict__ pt) {
+    int64_t Nall, PeerTable *__restrict__ pt, int verify) {
     // G <= TB_G exchanging workgroups (what is provably co-resident on this device), block G = the
     // epoch-end reduction
     if ((int)blockIdx.x == G) {   // epoch end: reduce + clear the M-step records (own CU)
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         q0[j] = ok ? wts[i] : 0.0f;
     }
     const TbSolved s = trajb_solve<E, TB_BLOCK>(sh, wm, l, q0, ev, true, b, G, Nall, tol, K, out_iters, trace,
-                                                ws, dbg, pt);
+                                                ws, dbg, pt, verify != 0);
     // a wait that timed out (RLVI_ST_TIMEOUT: the workgroups were not all resident) leaves the
     // caller's residuals and pi as they were -- the host raises on the status; it never hands out garbage
     if (s.dead) return;
@@ -77,12 +77,15 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
     }
 }
 
-// Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if not applicable.
+// Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if not applicable.  dry_run: only say
+// whether a launch would be admitted (rlvi_estep_sharded_check: every rank asks before the first
+// collective launch, so that no rank launches a solve that a peer cannot join).
 // (Round 1 had a node-per-workgroup form for 4096 <= N < 12 288 -- 240 workgroups of 1024 threads,
 //  0.5 us ahead at N = 8192; it needed a whole CU per workgroup to be free and was retired.)
 int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int maxiter,
                            int32_t *out_iters, float *trace, void *ws, hipStream_t st,
-                           float *mstep_out, double mstep_scale, int *rc, int64_t n_all, int sharded) {
+                           float *mstep_out, double mstep_scale, int *rc, int64_t n_all, int sharded,
+                           int dry_run) {
     const int mode = tune_get("RLVI_ESTEP_TRAJB", 1);
     const int64_t nmin = tune_get("RLVI_ESTEP_TRAJB_NMIN", 4096);
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin) return 0;
@@ -90,52 +93,49 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     // 256 threads measured 2-3 us per call ahead up to N = 262 144, level at 524 288, 1 us behind
     // from 1e6 on (whole step / eager call, hipGraph): 512 threads only for slices beyond 4096
     const int blk = tune_get("RLVI_TB_BLOCK", 0);
-    unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+    unsigned long long *dbg = (debug && !dry_run) ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
     const int extra = mstep_out != nullptr ? 1 : 0;
-    // The exchanging workgroups wait for each other, so all of them (and the reduction workgroup)
-    // must be resident at once: G = min(TB_G, what the occupancy query promises for this kernel
-    // on this device, less the reduction workgroup).  Too few for the slice to fit: not applicable
-    // (the iterative kernel takes over).
     const int64_t Nall = sharded ? n_all : N;
-    PeerTable *pt = sharded ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
+    PeerTable *pt = (sharded && !dry_run) ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
+    const int verify = tune_get("RLVI_TJ_VERIFY", 0);      // 1: always run the verification round
     int launched = 0;
+    // The exchanging workgroups wait for each other, so all of them (and the reduction workgroup) must
+    // be resident at once: a geometry (E samples per thread, B threads) runs on G = min(TB_G, what
+    // coop_cap proves co-resident for THIS instantiation on this device -- 1/S of it when S processes
+    // share the device --, less the reduction workgroup) workgroups and is admitted when G >= TJ_MAXK
+    // (node k is reduced by workgroup k) and the slice N/G fits E x B.  The candidates are tried in the
+    // order of their slice length, so with the whole device available the choice is the one measured
+    // fastest (the smallest slice that holds N/256), and with fewer co-resident workgroups a fatter
+    // instantiation takes the longer slices.
 #define RLVI_TB(E_, B_)                                                                           \
     do {                                                                                          \
+        if (launched) break;                                                                      \
         auto kern = estep_trajb_kernel<E_, B_>;                                                   \
         int G = coop_cap(kern, B_) - extra;                                                       \
         if (G > TB_G) G = TB_G;                                                                   \
-        if (G >= TJ_MAXK && (N + G - 1) / G <= (int64_t)(E_) * (B_)) {   /* node k is reduced by workgroup k */                                  \
-            *rc = launch(kern, dim3((unsigned)(G + extra)), dim3(B_), 0, st, res, wts, N, tol, maxiter, \
-                         out_iters, trace, ws, mstep_out, mstep_scale, dbg, G, Nall, pt);         \
+        if (G >= TJ_MAXK && (N + G - 1) / G <= (int64_t)(E_) * (B_)) {                            \
+            if (!dry_run)                                                                         \
+                *rc = launch(kern, dim3((unsigned)(G + extra)), dim3(B_), 0, st, res, wts, N, tol, maxiter, \
+                             out_iters, trace, ws, mstep_out, mstep_scale, dbg, G, Nall, pt, verify); \
+            else                                                                                  \
+                *rc = 0;                                                                          \
             launched = 1;                                                                         \
         }                                                                                         \
     } while (0)
-    const int64_t L = (N + TB_G - 1) / TB_G;      // slice at the full width
-    if (blk == 512 || (blk == 0 && L > 256 * 16)) {
-        if (L <= 512 * 2) RLVI_TB(2, 512);
-        else if (L <= 512 * 4) RLVI_TB(4, 512);
-        else if (L <= 512 * 6) RLVI_TB(6, 512);
-        else if (L <= 512 * 8) RLVI_TB(8, 512);
-        else if (L <= 512 * 12) RLVI_TB(12, 512);
-        else if (L <= 512 * 16) RLVI_TB(16, 512);
-    } else {
-        if (L <= 256 * 1) RLVI_TB(1, 256);
-        else if (L <= 256 * 2) RLVI_TB(2, 256);
-        else if (L <= 256 * 3) RLVI_TB(3, 256);
-        else if (L <= 256 * 4) RLVI_TB(4, 256);
-        else if (L <= 256 * 6) RLVI_TB(6, 256);
-        else if (L <= 256 * 8) RLVI_TB(8, 256);
-        else if (L <= 256 * 10) RLVI_TB(10, 256);
-        else if (L <= 256 * 12) RLVI_TB(12, 256);
-        else if (L <= 256 * 16) RLVI_TB(16, 256);
-        else if (L <= 256 * 24) RLVI_TB(24, 256);
-        else if (L <= 256 * 32) RLVI_TB(32, 256);
+    // Sharded over several GPUs: ONLY the 256-thread instantiations.  The first round's record width
+    // (7 granules with the third- and fourth-order sums, rlvi_trajb.h) and the recurrence variant hang on
+    // the workgroup size, and the ranks' shards -- hence their geometries -- may differ: with one
+    // workgroup size everywhere every rank pushes and polls the same records and runs the same chain.
+    const bool only256 = sharded || blk == 256;
+    const bool only512 = !sharded && blk == 512;
+    if (!only512) {
+        RLVI_TB(1, 256); RLVI_TB(2, 256); RLVI_TB(3, 256); RLVI_TB(4, 256); RLVI_TB(6, 256); RLVI_TB(8, 256);
+        RLVI_TB(10, 256); RLVI_TB(12, 256); RLVI_TB(16, 256);
     }
-    if (!launched) {
-        // fewer co-resident workgroups than TB_G: the fattest instantiations take longer slices
-        RLVI_TB(16, 512);
-        if (!launched) RLVI_TB(32, 256);
+    if (!only256) {
+        RLVI_TB(2, 512); RLVI_TB(4, 512); RLVI_TB(6, 512); RLVI_TB(8, 512); RLVI_TB(12, 512); RLVI_TB(16, 512);
     }
+    if (!only512) { RLVI_TB(24, 256); RLVI_TB(32, 256); }
 #undef RLVI_TB
     return launched;
 }

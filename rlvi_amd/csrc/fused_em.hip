@@ -52,7 +52,7 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     const float *__restrict__ logits, const int64_t *__restrict__ labels, float *__restrict__ loss_rows,
     float *__restrict__ pi, int64_t B, int C, float inv_scale, float tol, int K,
     float *__restrict__ grad, float *__restrict__ out, int32_t *__restrict__ out_iters, void *ws,
-    unsigned long long *__restrict__ dbg, int G) {
+    unsigned long long *__restrict__ dbg, int G, int verify) {
     constexpr int V = 4, LG = 4;                                  // floats per lane vector, lanes per row
     constexpr int NI = KMAX;                                      // 1-KiB pieces per tile (max)
     constexpr int WTILE = NI * 1024;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     float l1[1], ev1[1];
     l1[0] = erow < B ? nll[etid] : __builtin_inff();
     const TbSolved sol = trajb_solve<1, FE_EB, FE_THREADS / FE_EB>(sh, wm, l1, q0, ev1, active, b, G, B, tol, K, out_iters,
-                                               nullptr, ws, dbg);
+                                               nullptr, ws, dbg, nullptr, verify != 0);
     const float pmax = tb_pmax(sol);
     FE_STAMP(4);   // solved
 
@@ -367,6 +367,7 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
     const int nv = (int)C / 4, k = (nv + 3) / 4;
     const int debug = tune_get("RLVI_TJ_DEBUG", 0);
     unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+    const int verify = tune_get("RLVI_TJ_VERIFY", 0);
     int launched = 0;
 #define RLVI_FE(K_, X_)                                                                              \
     do {                                                                                             \
@@ -384,7 +385,7 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
         }                                                                                            \
         if (coop_cap(kern, FE_THREADS, lds) < G) break;     /* all G workgroups must be resident */  \
         *rc = launch(kern, dim3((unsigned)G), dim3(FE_THREADS), lds, st, logits, labels, loss_rows, pi, B, \
-                     (int)C, inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G);             \
+                     (int)C, inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G, verify);     \
         launched = 1;                                                                                \
     } while (0)
     if (k <= 4) RLVI_FE(4, false);

@@ -111,6 +111,13 @@ extern "C" int rlvi_workspace_set_peers(void *ws, int rank, int world, void *con
     // the sharded solves start cold, and alike on every rank
     hipError_t e = hipMemsetAsync(static_cast<char *>(ws) + WS_PEER_OFF, 0, WS_PEER_BYTES, st);
     if (e != hipSuccess) return (int)e;
+    // ... and with a clean inbox: the round counter restarts at 0, so records an earlier set-up left in
+    // the inbox (tags 1..n) would pass for the new rounds' records.  (The caller's barrier over the ranks
+    // between this call and the first sharded call keeps a peer's push from racing this memset.)
+    if (inboxes && inboxes[rank]) {
+        e = hipMemsetAsync(inboxes[rank], 0, PEER_INBOX_BYTES, st);
+        if (e != hipSuccess) return (int)e;
+    }
     e = hipMemcpyAsync(static_cast<char *>(ws) + WS_PEER_OFF, &t, sizeof(t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(st);

@@ -160,7 +160,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
     TbShared<TB_BLOCK / WAVE> &sh, const TbWarm &wm, const float (&l)[E], const float (&q0)[E],
     float (&ev)[E], const bool active, const int b, const int G, const int64_t N, const float tol,
     const int K, int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
-    unsigned long long *__restrict__ dbg, PeerTable *__restrict__ pt = nullptr) {
+    unsigned long long *__restrict__ dbg, PeerTable *__restrict__ pt = nullptr, const bool verify = false) {
     int dbgi = 0;
 #define TB_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
     TB_STAMP();
@@ -306,7 +306,9 @@ __device__ __forceinline__ TbSolved trajb_solve(
         // (only the 256-thread geometry, i.e. slices up to 8192 samples: the fat 512-thread forms have
         //  no registers to spare for three more accumulator sets)
         constexpr bool HI_OK = TB_BLOCK == 256;
-        const bool hi_round = HI_OK && round == 0 && trace == nullptr;
+        // (verify -- RLVI_TJ_VERIFY=1 -- forces the verification round: no fourth-order first round, no
+        //  acceptance on estimated step errors; the tests hold the two paths against each other)
+        const bool hi_round = HI_OK && round == 0 && trace == nullptr && !verify;
         if (active) {     // (threads past TB_BLOCK, if the caller has any, only follow the barriers)
             if constexpr (HI_OK) {
                 if (hi_round) sums(std::true_type{}); else sums(std::false_type{});

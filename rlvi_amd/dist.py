@@ -50,26 +50,79 @@ def ragged():
     return _RAGGED
 
 
+_SHARERS = {}
+
+
+def declare_device_sharing(group=None):
+    """Collective (once per process group; later calls return the cached count): how many ranks of the
+    group drive the SAME physical GPU as this one?  The kernels whose workgroups wait for each other size
+    their grids from an occupancy query that sees one process only; S processes that each take what the
+    query promises can together ask for more workgroups than the device holds, and every grid then waits
+    for slots another one occupies until the spin bound ends them (RLVI_ST_TIMEOUT).  The ranks compare
+    (host name, PCI bus id of the current device) and every rank that shares its GPU with S - 1 others tells
+    the library to take 1/S of the proven capacity (RLVI_DEVICE_SHARERS).  One process per GPU -- the normal
+    case -- gives 1 and changes nothing.  An explicit RLVI_DEVICE_SHARERS in the environment wins.
+    Called by train_rlvi, setup_peers and bench.py; on a machine without a GPU it returns 1."""
+    if not is_dist():
+        return 1
+    key = id(group) if group is not None else 0
+    if key in _SHARERS:
+        return _SHARERS[key]
+    import ctypes
+    import os
+    import socket
+    ident = None
+    if torch.cuda.is_available():
+        from . import _lib
+        buf = ctypes.create_string_buffer(64)
+        if _lib.load().rlvi_device_pci_bus_id(buf, 64) == 0:
+            ident = (socket.gethostname(), buf.value.decode())
+    idents = [None] * dist.get_world_size(group)
+    dist.all_gather_object(idents, ident, group=group)
+    n = sum(1 for x in idents if x is not None and x == ident) if ident is not None else 1
+    if ident is not None and "RLVI_DEVICE_SHARERS" not in os.environ:
+        from . import _lib
+        _lib.check(_lib.load().rlvi_tune_set(b"RLVI_DEVICE_SHARERS", max(n, 1)), "rlvi_tune_set")
+    _SHARERS[key] = max(n, 1)
+    return _SHARERS[key]
+
+
 _OWNER = None
 
 
-def set_owner_sharding(owned, ws, peers):
+def set_owner_sharding(owned, ws, peers, n_all=None, with_scalars=True):
     """Opt in to the collective-free epoch end of train_rlvi: every rank owns a FIXED set of samples
     (`owned`: 1-D int64 device tensor of their indexes; every sample owned by exactly one rank; the rank's
     loader yields only those) and keeps residuals / weights of its own samples only.  The E-step and the
     threshold then run sharded (ops.estep_sharded / threshold_truncate_sharded on the compacted owned
     entries: the kernels exchange their totals through `peers`' inboxes), nothing is gathered, and after
     the call only the OWNED entries of residuals / weights are meaningful on a rank.  `ws`: the workspace
-    `peers = setup_peers(ws)` was set up on.  None switches back to the replicated form."""
+    `peers = setup_peers(ws)` was set up on.  None switches back to the replicated form.
+    n_all: the length of the caller's residuals / weights vectors (= the number of samples over all ranks);
+    when given, the ranks' shares must add up to it (the E-step divides by it).  Shares may differ in
+    length: the sharded solve runs the same workgroup size on every rank."""
     global _OWNER
     if owned is not None and is_dist():
-        # a collective: the sharded kernels take 4096 .. 2 097 152 samples per rank, and a rank that cannot
-        # launch would leave the others waiting for it -- so every rank learns every rank's share now
+        # a collective: a rank that cannot launch (share too small / too large for the sharded kernels on
+        # the co-residency this process is entitled to) would leave the others waiting for it -- so every
+        # rank asks the library now and learns every rank's answer
+        from . import _lib
         from ._lib import RlviError
-        sizes = [None] * dist.get_world_size()
-        dist.all_gather_object(sizes, int(owned.numel()))
-        if min(sizes) < 4096 or max(sizes) > 2097152:
-            raise RlviError(f"owner sharding needs 4096 .. 2097152 samples on every rank, got {sizes}")
+        mine = int(owned.numel())
+        total = [None] * dist.get_world_size()
+        dist.all_gather_object(total, mine)
+        n_sum = sum(total)
+        if n_all is not None and n_sum != int(n_all):
+            raise RlviError(f"owner sharding: the ranks' shares {total} add up to {n_sum}, not to the "
+                            f"{int(n_all)} samples of the vectors (every sample needs exactly one owner)")
+        ok = (mine > 1024 and
+              _lib.load().rlvi_estep_sharded_check(mine, n_sum, 40, 1 if with_scalars else 0) == 0)
+        oks = [None] * dist.get_world_size()
+        dist.all_gather_object(oks, bool(ok))
+        if not all(oks):
+            raise RlviError("owner sharding: the sharded E-step / threshold cannot launch on every rank "
+                            f"(shares {total}, launchable {oks}; 4096 .. 2097152 samples per rank, fewer at "
+                            "the upper end when several ranks share one GPU)")
     _OWNER = None if owned is None else (owned, ws, peers)
 
 
@@ -111,6 +164,20 @@ def mean_scalars(t, group=None):
         dist.all_reduce(t, group=group)
         t /= dist.get_world_size(group)
     return t
+
+
+def rank0_value(x, group=None):
+    """Rank 0's value of a host scalar on every rank (one small broadcast).  For quantities that steer
+    control flow -- the epoch driver's val_acc and the `overfit` flag derived from it: under DDP a model with
+    BatchNorm evaluates slightly differently on every rank (the running statistics are only broadcast at
+    the start of a forward), and a discrete decision that differs between ranks would let one rank
+    truncate its weights alone, or enter a sharded kernel alone and wait for the others."""
+    if not is_dist():
+        return x
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return float(t.item())
 
 
 def shard_range(n, rank, world):
@@ -246,6 +313,8 @@ class Peers:
         self.rank = dist.get_rank(group) if multi else 0
         self.own, self.mapped = None, []
         self._ws = ws
+        # ranks that share a GPU (debugging on a one-GPU box) split its co-residency between them
+        declare_device_sharing(group)
         err, raw = None, None
         try:
             if self.world > 8:
@@ -279,6 +348,7 @@ class Peers:
                         ptrs[r] = p.value
                 _lib.check(L.rlvi_workspace_set_peers(ws.ptr, self.rank, self.world, ptrs, ops._stream_ptr()),
                            "rlvi_workspace_set_peers")
+                ws.peers_stale = False
             except Exception as e:  # noqa: BLE001
                 err = repr(e)
         elif err is None:

@@ -220,7 +220,7 @@ def run(n_train=16384, n_val=2048, n_test=2048, batch_size=1024, n_epoch=9, nois
     val_acc_old = val_acc_old_old = 0.0
     write = log_path and rank == 0
     # main.py:257-262: the initial model
-    test_acc = evaluate_fn(test_loader, model, device)
+    test_acc = rdist.rank0_value(evaluate_fn(test_loader, model, device))
     logs = [dict(epoch=0, time_ep=0.0, tau=0.0, fix=False, clean=100.0, corr=0.0, train_acc=0.0,
                  val_acc=0.0, test_acc=test_acc, lr=optimizer.param_groups[0]["lr"], kept=n_train)]
     if write:
@@ -233,7 +233,9 @@ def run(n_train=16384, n_val=2048, n_test=2048, batch_size=1024, n_epoch=9, nois
         lr_now = optimizer.param_groups[0]["lr"]
         train_acc, threshold = train_fn(train_loader, net, optimizer, residuals,
                                         sample_weights, overfit, threshold)         # main.py:277-280
-        val_acc = evaluate_fn(val_loader, model, device)
+        # (under DDP every rank evaluates its own replica; BatchNorm's running statistics may differ by a
+        #  rank's last batch, so the number that steers `overfit` is rank 0's on every rank)
+        val_acc = rdist.rank0_value(evaluate_fn(val_loader, model, device))
         if not overfit:                                            # main.py:283-288
             if epoch > 2:
                 overfit = val_acc < 0.5 * (val_acc_old + val_acc_old_old)
@@ -241,7 +243,7 @@ def run(n_train=16384, n_val=2048, n_test=2048, batch_size=1024, n_epoch=9, nois
         if scheduler is not None:
             scheduler.step()                                       # main.py:322
         time_ep = time.time() - t0
-        test_acc = evaluate_fn(test_loader, model, device)
+        test_acc = rdist.rank0_value(evaluate_fn(test_loader, model, device))
         mask = (sample_weights > threshold).cpu().numpy()          # main.py:343
         clean, corr = get_ratio_corrupted(mask, noise_mask[tr])
         rec = dict(epoch=epoch, time_ep=time_ep, tau=float(threshold), fix=bool(overfit),

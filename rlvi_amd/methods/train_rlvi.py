@@ -60,6 +60,8 @@ def train_rlvi(train_loader, model, optimizer,
     owner = rdist.owner_sharding() if rdist.world_size() > 1 else None
     ws = owner[1] if owner is not None else ops.workspace(weights.device, weights.shape[0], 0)
     world = rdist.world_size()
+    if world > 1:
+        rdist.declare_device_sharing()      # (collective once per group, cached afterwards)
     visited, sizes = [], []
 
     for (images, labels, indexes) in train_loader:

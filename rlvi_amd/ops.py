@@ -38,6 +38,9 @@ class Workspace:
         self.nbytes = int(L.rlvi_workspace_bytes(self.max_n, self.max_b))
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         assert self.buf.data_ptr() % 256 == 0
+        # a sharded call that timed out leaves the ranks' round counters / warm-start state out of step:
+        # further sharded calls are refused until rlvi_amd.dist.setup_peers(ws) has run again (all ranks)
+        self.peers_stale = False
         _lib.check(L.rlvi_workspace_init(_ptr(self.buf), self.nbytes, _stream_ptr()),
                    "rlvi_workspace_init")
 
@@ -61,6 +64,8 @@ class Workspace:
         st = self.status()
         if st & mask:
             self.clear_status()
+            if st & _lib.ST_TIMEOUT:
+                self.peers_stale = True
             raise _lib.RlviError(f"{what}: device status {st}: {_lib.status_message(st & mask)}")
         return st
 
@@ -178,6 +183,12 @@ def mstep_reduce(scale=1.0, out=None, ws=None, device=None):
     return out
 
 
+def _refuse_stale_peers(ws):
+    if getattr(ws, "peers_stale", False):
+        raise _lib.RlviError("a sharded call on this workspace timed out earlier: the ranks' round counters may "
+                             "differ now -- run rlvi_amd.dist.setup_peers(ws) again on every rank first")
+
+
 def estep_sharded(residuals, weights, n_all, tol=1e-3, maxiter=40, iters=None, ws=None, batches=0, out=None):
     """update_sample_weights (train_rlvi.py:14-38) with the samples sharded over the ranks: this rank's
     slice of residuals / weights in place, n_all samples over all ranks.  A collective over the ranks of
@@ -191,6 +202,7 @@ def estep_sharded(residuals, weights, n_all, tol=1e-3, maxiter=40, iters=None, w
             raise ValueError("residuals / weights must be contiguous 1-D fp32 tensors")
     if ws is None:
         raise ValueError("the sharded E-step needs the workspace whose peer table was set up")
+    _refuse_stale_peers(ws)
     rc = L.rlvi_estep_sharded_f32(_ptr(residuals), _ptr(weights), weights.shape[0], int(n_all), float(tol),
                                   int(maxiter), int(batches), _ptr(out) if batches > 0 else None, _ptr(iters),
                                   ws.ptr, _stream_ptr())
@@ -207,6 +219,7 @@ def threshold_truncate_sharded(weights, n_all, threshold, alpha=0.05, want_mask=
         raise ValueError("weights must be a contiguous 1-D fp32 tensor")
     if ws is None:
         raise ValueError("the sharded threshold needs the workspace whose peer table was set up")
+    _refuse_stale_peers(ws)
     thr = torch.as_tensor(threshold, dtype=torch.float32, device=weights.device).reshape(1).clone()
     mask = torch.empty(weights.shape[0], dtype=torch.uint8, device=weights.device) if want_mask else None
     kept = torch.zeros(1, dtype=torch.int64, device=weights.device)

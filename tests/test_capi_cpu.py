@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.rlvi_abi_version() == 1
+    assert lib.rlvi_abi_version() == 2
     assert lib.rlvi_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.rlvi_error_string(code) not in (b"ok", b"unknown rlvi error")
@@ -155,3 +155,43 @@ def test_driver_models_and_schedule():
     assert net(torch.zeros(2, 3, 32, 32)).shape == (2, 10)
     assert sum(p.numel() for p in net.parameters()) == 11173962 - 0   # CIFAR ResNet18, 10 classes
     assert driver.LeNet(1, 10)(torch.zeros(2, 1, 28, 28)).shape == (2, 10)
+
+
+def test_bench_plans_its_ranks_and_says_what_it_could_not_measure():
+    """`python bench.py --gpus N` becomes N ranks itself; with fewer devices than asked for it runs on the
+    visible ones and says so (never an M-GPU number in N's clothing).  Here (no GPU): the planning rule, and
+    the end-to-end record of a box with no device at all -- one JSON line, n_gpus 0, exit code 3."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.plan_ranks(8, 8, False) == (8, None)
+    assert bench.plan_ranks(2, 8, False) == (2, None)
+    assert bench.plan_ranks(8, 1, False) == (1, "8 requested, 1 visible")
+    assert bench.plan_ranks(4, 2, False) == (2, "4 requested, 2 visible")
+    assert bench.plan_ranks(3, 1, True) == (3, None)            # --same-device: ranks share cuda:0
+    assert bench.plan_ranks(2, 0, False) == (0, "2 requested, 0 visible")
+    import torch
+    if torch.cuda.device_count() == 0:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                            "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert p.returncode == 3, p.stderr[-1000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 0 and rec["value"] is None and rec["not_measured"] == "2 requested, 0 visible"
+
+
+def test_package_import_selects_the_dmabuf_ipc_mode(monkeypatch):
+    """Multi-process GPU work (RCCL, the peers' inboxes) needs HSA_ENABLE_IPC_MODE_LEGACY=0 before the runtime
+    starts: importing the package defaults it and never overrides an explicit setting."""
+    import importlib
+    import rlvi_amd
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    importlib.reload(rlvi_amd)
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    importlib.reload(rlvi_amd)
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"

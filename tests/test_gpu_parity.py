@@ -1025,7 +1025,7 @@ def test_bench_two_ranks_on_one_gpu(mode, gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "32768", "--backend", "gloo",
@@ -1041,6 +1041,79 @@ def test_bench_two_ranks_on_one_gpu(mode, gpu):
     assert res["config"]["estep_dist"] == ("sharded" if mode == "auto" else "replicated"), res["config"]
     if mode == "auto":
         assert res["config"]["launch"] == "hipGraph"
+    assert res["value"] > 0
+
+
+def _run_bench(args, timeout=400, env_extra=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, [json.loads(ln) for ln in lines]
+
+
+def test_bench_spawns_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's command): the parent starts
+    two fresh ranks before it touches the GPU and passes rank 0's one JSON line through; here the ranks
+    share cuda:0 (gloo for the host-side collectives).  n_gpus says 2, the sharded E-step passed its
+    start-up self-check (each rank took half of the device's co-residency: RLVI_DEVICE_SHARERS), no
+    device status in any leg."""
+    p, recs = _run_bench(["--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                          "--rows", "32768", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(recs) == 1
+    res = recs[0]
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and "not_measured" not in res
+    assert res["device_status"] == 0 and "device_status_events" not in res
+    assert res["config"]["estep_dist"] == "sharded" and res["config"]["launch"] == "hipGraph"
+    assert res["config"]["n_samples"] == 65536 and res["config"]["estep_dist_setup_s"] < 30.0
+
+
+def test_bench_strong_scaling_splits_the_same_batch(gpu):
+    """--scaling strong: the 65 536-row batch is split over the ranks (32 768 rows each, N = 65 536)."""
+    p, recs = _run_bench(["--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                          "--scaling", "strong", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = recs[0]
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["device_status"] == 0
+    assert res["config"]["rows_per_gpu"] == 32768 and res["config"]["n_samples"] == 65536
+    assert res["parts"]["estep_iters"] >= 1 and res["value"] > 0
+
+
+def test_bench_with_fewer_devices_than_asked_says_so(gpu):
+    """--gpus 2 on a box with one GPU: the run is made on the one device and the record says
+    n_gpus 1 / not_measured, instead of a one-GPU number under n_gpus 2."""
+    torch, _, _ = gpu
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one visible GPU")
+    p, recs = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = recs[0]
+    assert res["n_gpus"] == 1 and res["not_measured"] == "2 requested, 1 visible"
+    assert res["parity"]["ok"] and res["device_status"] == 0
+
+
+def test_bench_absent_peer_lands_on_the_replicated_path_in_bounded_time(gpu):
+    """A sharded path that fails costs a bounded time and nothing else: rank 1 never joins the start-up
+    self-check, rank 0's wait on its records runs into the bound (100 x the spin bound = 10 s by default),
+    both ranks agree on the failure and the bench is timed with the replicated E-step -- the status that
+    the failed wait raised stays in the JSON line."""
+    p, recs = _run_bench(["--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                          "--rows", "32768", "--no-cpu-baseline", "--debug-absent-peer", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = recs[0]
+    assert res["config"]["estep_dist"] == "replicated"
+    assert "self-check failed" in res["config"]["estep_dist_note"]
+    assert res["config"]["estep_dist_setup_s"] < 30.0
+    ev = res["device_status_events"]
+    assert any(e["leg"] == "sharded self-check" and e["status"] & 2 for e in ev)
+    assert all(e["leg"] == "sharded self-check" for e in ev)      # the timed legs themselves ran clean
     assert res["value"] > 0
 
 
@@ -1149,14 +1222,13 @@ def test_train_rlvi_two_ranks_on_one_gpu_reproduces_g4(gpu):
     assert all(r[1] == "ok" for r in results), results
 
 
-def _sharded_estep_worker(rank, world, port, q, n_local, cap):
+def _sharded_estep_worker(rank, world, port, q, sizes, cap):
     import os as _os
     import sys as _sys
     root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
     _sys.path.insert(0, root)
     _os.environ["MASTER_ADDR"] = "127.0.0.1"
     _os.environ["MASTER_PORT"] = str(port)
-    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     import torch as _torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -1166,11 +1238,17 @@ def _sharded_estep_worker(rank, world, port, q, n_local, cap):
         if cap:
             _lib.check(_lib.load().rlvi_tune_set(b"RLVI_COOP_CAP", cap), "tune")
         dev = _torch.device("cuda:0")
-        N = n_local * world
-        ws = _ops.Workspace(dev, n_local * world, 0)
-        peers = rdist.setup_peers(ws)
+        N = int(sum(sizes))
+        ws = _ops.Workspace(dev, N, 0)
+        peers = rdist.setup_peers(ws)          # (also: the ranks find out that they share one GPU)
+        assert rdist.declare_device_sharing() == world
         out = []
-        lo, hi = rank * n_local, (rank + 1) * n_local
+        lo = int(sum(sizes[:rank]))
+        hi = lo + int(sizes[rank])
+        # every rank asks whether its launch would be admitted, and the ranks compare, before anybody launches
+        can = [None] * world
+        dist.all_gather_object(can, _lib.load().rlvi_estep_sharded_check(hi - lo, N, 40, 0) == 0)
+        assert all(can), can
         if rank == 0:
             # one rank alone does something else with its workspace (an E-step and a threshold over N values):
             # the sharded calls keep their own warm-start state, so the ranks still agree
@@ -1210,31 +1288,36 @@ def _sharded_estep_worker(rank, world, port, q, n_local, cap):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,n_local,cap", [(2, 32768, 0), (2, 20000, 100), (3, 16384, 80)])
-def test_sharded_estep_ranks_on_one_gpu(world, n_local, cap, gpu, oracle):
+@pytest.mark.parametrize("sizes,cap", [((32768, 32768), 0), ((20000, 20000), 100), ((16384, 16384, 16384), 80),
+                                       ((300000, 20000), 0), ((9000, 52000, 4536), 0)])
+def test_sharded_estep_ranks_on_one_gpu(sizes, cap, gpu, oracle):
     """SURVEY 8(e), the E-step sharded over ranks: `world` processes on cuda:0, each with its own slice of
     the samples; the kernels' reducer workgroups push their per-node totals into the other ranks' inboxes
     (IPC-mapped uncached device memory; over xGMI when the ranks sit on different GPUs -- one GPU here,
     so this checks the protocol, the mapping and the arithmetic, not the fabric).  Every rank must come out
     with its slice of the oracle's pi on the WHOLE vector, the same iteration count, a clean status --
     cold, warm (the same vector again) and on new data -- and the sharded threshold / truncation on that pi
-    with the oracle's threshold, mask and kept count bit for bit."""
+    with the oracle's threshold, mask and kept count bit for bit.  Shards of different length (the ranks
+    then run different slice lengths and grids, but the same workgroup size, record layout and chain) and
+    no pinned cap in three of the cases: the ranks find out by themselves that they share the GPU and each
+    takes its share of the co-residency."""
     import socket
     import torch.multiprocessing as mp
+    world = len(sizes)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_estep_worker, args=(r, world, port, q, n_local, cap)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_estep_worker, args=(r, world, port, q, sizes, cap)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in results), [r[1] for r in results]
-    N = n_local * world
+    N = int(sum(sizes))
     for i, (kind, seed) in enumerate((("bimodal", 1), ("bimodal", 1), ("exp", 2), ("heavy", 3), ("bimodal", 4))):
         r_all = synth.residual_vector(kind, N, seed=seed)
         w_all = np.random.default_rng(seed).random(N).astype(np.float32)
@@ -1283,7 +1366,6 @@ def _owner_worker(rank, world, port, q, N, D, C, per_rank, epochs):
     _sys.path.insert(0, _os.path.join(root, "tests"))
     _os.environ["MASTER_ADDR"] = "127.0.0.1"
     _os.environ["MASTER_PORT"] = str(port)
-    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     import torch as _torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -1293,7 +1375,7 @@ def _owner_worker(rank, world, port, q, N, D, C, per_rank, epochs):
         from rlvi_amd import dist as rdist
         from rlvi_amd.methods import train_rlvi
         import test_gpu_parity as T
-        _lib.check(_lib.load().rlvi_tune_set(b"RLVI_COOP_CAP", 100), "tune")   # two processes share the GPU
+        # (no pinned RLVI_COOP_CAP: setup_peers finds the two ranks on one GPU and halves each one's share)
         dev = _torch.device("cuda:0")
         X, y = T._owner_data(N, D, C)
         Xd, yd = _torch.from_numpy(X).to(dev), _torch.from_numpy(y).to(dev)
@@ -1305,7 +1387,9 @@ def _owner_worker(rank, world, port, q, N, D, C, per_rank, epochs):
         ws = _ops.Workspace(dev, N, per_rank)
         peers = rdist.setup_peers(ws)
         owned = _torch.arange(rank, N, world, device=dev)
-        rdist.set_owner_sharding(owned, ws, peers)
+        with pytest.raises(_lib.RlviError, match="add up"):       # every sample needs exactly one owner
+            rdist.set_owner_sharding(owned[:-1] if rank == 0 else owned, ws, peers, n_all=N)
+        rdist.set_owner_sharding(owned, ws, peers, n_all=N)
         thr, log = 0.0, []
         for ep in range(epochs):
             loader = [(Xd[ix], yd[ix], _torch.from_numpy(ix).to(dev)) for ix in T._owner_batches(rank, world, N, per_rank, ep)]

@@ -221,3 +221,61 @@ def test_peer_setup_fails_loudly_and_on_every_rank_without_a_gpu():
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in results), results
+
+
+def _worker_driver_overfit(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rlvi_amd import driver
+        # what BatchNorm's per-rank running statistics can do to a replica's evaluation: the ranks see
+        # slightly different accuracies -- here so different that rank 1 alone would never set `overfit`
+        seq = {0: [50.0, 60.0, 70.0, 30.0, 30.0, 30.0, 30.0], 1: [50.0, 60.0, 70.0, 71.0, 72.0, 73.0, 74.0]}[rank]
+        calls = {"n": 0}
+        flags = []
+
+        def evaluate_fn(loader, model, device):
+            # (called for test, then per epoch val + test: the val calls are the odd ones)
+            calls["n"] += 1
+            k = calls["n"]
+            return seq[min((k - 2) // 2, len(seq) - 1)] if k >= 2 and k % 2 == 0 else 10.0 + rank
+
+        def train_fn(loader, net, opt, residuals, weights, overfit, threshold):
+            flags.append(bool(overfit))
+            return 0.0, threshold
+        logs = driver.run(n_train=64, n_val=16, n_test=16, batch_size=16, n_epoch=7, device="cpu",
+                          train_fn=train_fn, evaluate_fn=evaluate_fn, schedule=False)
+        mine = torch.tensor([float(f) for f in flags] + [r["val_acc"] for r in logs] + [r["test_acc"] for r in logs],
+                            dtype=torch.float64)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1]), (both[0], both[1])      # same decisions, same log on every rank
+        assert flags == [False, False, False, False, True, True], flags   # rank 0's numbers: overfit after epoch 4
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + repr(e) + "\n" + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_epoch_driver_takes_rank_identical_overfit_decisions():
+    """The driver's `overfit` switch (main.py:283-288) is a discrete decision on val_acc; under DDP every
+    rank evaluates its own replica, and replicas with BatchNorm differ.  Rank 0's value steers every rank:
+    with evaluation functions that disagree between the ranks, both ranks pass the same `overfit` flags to
+    the training function and log the same accuracies."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_driver_overfit, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in results), results
