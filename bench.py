@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)")
@@ -67,6 +67,8 @@ def parse():
                     help="debug: run the residual exchange (and its process group) at world size 1")
     ap.add_argument("--profile-only", action="store_true",
                     help="warmup + timed steps only (for rocprofv3 runs)")
+    ap.add_argument("--no-epoch-legs", action="store_true",
+                    help="skip the end-to-end epoch timings (parts.epoch: plug-in vs stock eager torch)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="world > 1: weak = --rows rows on EVERY rank (N = rows x world samples); strong = --rows "
                          "rows in all, rows / world on every rank (N = rows samples)")
@@ -165,6 +167,114 @@ def make_inputs(torch, dev, B, C, N, rank):
     weights = torch.from_numpy(wrng.random(N).astype(np.float32)).to(dev)
     residuals = torch.zeros(N, dtype=torch.float32, device=dev)
     return d, labels, idx_local, logits, grads, weights, residuals
+
+
+def eager_torch_epoch(loader, model, optimizer, residuals, weights, tol=1e-3, maxiter=40):
+    """What a user of the reference gets on this GPU today: the statements of one train_rlvi epoch
+    (deep-learning/methods/train_rlvi.py:79-99 with utils.accuracy, :14-38) as stock PyTorch-ROCm eager ops
+    -- written here, no reference file travels -- to stand next to the plug-in's epoch time."""
+    import torch
+    import torch.nn.functional as F
+    hits_pct, batches = 0, 0
+    for images, labels, indexes in loader:
+        logits = model(images)
+        # top-1 of accuracy(logits, labels, topk=(1, 5)): softmax, top-5, compare (the top-5 figure is dropped)
+        top = F.softmax(logits, dim=1).topk(5, 1, True, True)[1].t()
+        match = top.eq(labels.view(1, -1).expand_as(top))
+        hits_pct = hits_pct + match[:1].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / labels.size(0))
+        batches += 1
+        nll = F.cross_entropy(logits, labels, reduction='none')
+        residuals[indexes] = nll
+        weighted = (nll * weights[indexes]).mean()
+        optimizer.zero_grad()
+        weighted.backward()
+        optimizer.step()
+    with torch.no_grad():          # the per-epoch E-step, one host sync per iteration (the `if error < tol`)
+        residuals.sub_(residuals.min())
+        e = torch.exp(-residuals)
+        avg = 0.95
+        for _ in range(maxiter):
+            ratio = avg / (1 - avg)
+            new = torch.div(ratio * e, 1 + ratio * e)
+            err = torch.norm(new - weights)
+            weights[:] = new
+            avg = weights.mean()
+            if err < tol:
+                break
+        weights.div_(weights.max())
+    return float(hits_pct) / float(batches)
+
+
+def epoch_legs(torch, dev, a):
+    """End-to-end epoch wall time through the plug-in -- the one performance quantity the reference itself
+    logs (time_ep, deep-learning/main.py:268,327) -- at BASELINE.json's cfg3 shape (LeNet on MNIST-shaped
+    synthetic images, N = 54 000) with batch 4096 and with the reference's own batch of 32, next to the
+    same epoch as stock eager PyTorch ops on the same GPU, and the host time of the M-step wrapper alone.
+    Data is resident on the device (images, labels, indexes); wall clock around a whole epoch including its
+    one host sync; median of 3 epochs after one warm-up epoch."""
+    from rlvi_amd import driver, ops
+    from rlvi_amd.methods import train_rlvi
+    N, C = 54000, 10
+    out = {}
+    x, y, _, _ = driver.synthetic_images(N, 1, C, 28, 0.5, "symmetric", seed=1)
+    x, y = x.to(dev), y.to(dev)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(0)
+    perm = torch.randperm(N, generator=gen).to(dev)
+
+    def make_loader(bs):
+        return [(x[perm[s:s + bs]], y[perm[s:s + bs]], perm[s:s + bs].contiguous()) for s in range(0, N, bs)]
+
+    def run(kind, loader):
+        torch.manual_seed(0)
+        model = driver.LeNet(1, C).to(dev)
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-3)
+        residuals = torch.zeros(N, device=dev)
+        weights = torch.ones(N, device=dev)
+        model.train()
+        times = []
+        for ep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if kind == "plugin":
+                train_rlvi(loader, model, opt, residuals, weights, False, 0)
+            else:
+                eager_torch_epoch(loader, model, opt, residuals, weights)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return sorted(times[1:])[1] * 1e3
+
+    for bs in (4096, 32):
+        loader = make_loader(bs)
+        out[f"b{bs}"] = {"batches": len(loader),
+                         "epoch_ms_plugin": run("plugin", loader),
+                         "epoch_ms_eager_torch": run("eager", loader)}
+        del loader
+    # host time of the M-step call alone at cfg3's 4096 x 10 (the kernel takes ~4 us: back-to-back calls on
+    # one stream are host-bound, so wall time / calls is what the host pays per batch)
+    z = torch.randn(4096, C, device=dev)
+    lab = torch.randint(0, C, (4096,), device=dev)
+    idx = perm[:4096].contiguous()
+    w, r = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    ws = ops.Workspace(dev, N, 4096)
+    loop = ops.MStepLoop(w, r, ws)
+    for name, fn in (("host_us_per_batch", lambda: loop(z, lab, idx)),
+                     ("host_us_per_batch_generic", lambda: ops.mstep_fwd_bwd(z, lab, idx, w, r, ws=ws,
+                                                                               accumulate=True))):
+        for _ in range(200):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3000):
+            fn()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        out[name] = t_host / 3000 * 1e6
+    ops.mstep_reduce(ws=ws)
+    out["note"] = ("LeNet, N=54000 MNIST-shaped synthetic images resident on the device; wall clock of one whole "
+                   "train_rlvi epoch (median of 3 after a warm-up epoch); eager_torch = the same statements "
+                   "as stock PyTorch-ROCm ops on this GPU")
+    return out
 
 
 def main():
@@ -553,6 +663,8 @@ def main():
             extra["mstep_4x_us"] = ms4 * 1e3
             extra["mstep_4x_frac"] = (B4 * (2 * C * 4 + 24) / (ms4 * 1e-3)) / HBM_PEAK
             del big, gbig
+        if not a.no_epoch_legs:
+            extra["epoch"] = epoch_legs(torch, dev, a)
     bytes_per_sample = 2 * C * 4 + 24
     achieved = B * bytes_per_sample / (ms_m * 1e-3)
     # HBM bytes per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE x2 on gfx950 +
@@ -588,40 +700,82 @@ def main():
         from oracle import rlvi_oracle as O
         ncpu = os.cpu_count() or 1
         w0 = w_before.cpu().numpy()
+        t_leg = time.perf_counter()
 
         def cpu_step(w_o, res_o):
             O.mstep(d0["logits"], d0["labels"], d0["idx"], w_o, res_o, scale_div=N)
             O.update_sample_weights(res_o, w_o)
 
-        # the box exposes more logical CPUs than the job's share: pick the OpenMP thread count
-        # that is actually fastest here (one untimed + one timed step each) and report it
-        best_t, best_dt = 1, None
-        for t in sorted({1, 4, 8, 16, 32, 64, ncpu}):
+        def median_time(fn, reps):
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
+
+        # the box exposes more logical CPUs than the job's share: pick the OpenMP thread count that is
+        # fastest here -- one untimed + three timed steps per candidate, the MEDIAN decides (a single
+        # timed step per candidate made the choice noise: 32 threads in round 1, 64 in round 2, a factor
+        # of two in the reported baseline on unchanged oracle code)
+        cal = {}
+        for t in (8, 16, 24, 32, 48, 64, 96, 128):
             if t > ncpu:
                 continue
             O.set_threads(t)
             w_o, res_o = w0.copy(), np.zeros(N, np.float32)
             cpu_step(w_o, res_o)
-            t0 = time.perf_counter()
-            cpu_step(w_o, res_o)
-            dt = time.perf_counter() - t0
-            if best_dt is None or dt < best_dt:
-                best_t, best_dt = t, dt
+            cal[t] = median_time(lambda: cpu_step(w_o, res_o), 3)
+        if not cal:
+            cal[ncpu] = None
+        best_t = min(cal, key=lambda t: cal[t] if cal[t] is not None else 0.0)
         O.set_threads(best_t)
         w_o, res_o = w0.copy(), np.zeros(N, np.float32)
-        n = 0
-        t0 = time.perf_counter()
+        cpu_step(w_o, res_o)
+        ts = []
+        t_start = time.perf_counter()
         while True:
+            t0 = time.perf_counter()
             cpu_step(w_o, res_o)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= a.cpu_seconds or n >= 5000:
+            ts.append(time.perf_counter() - t0)
+            el = time.perf_counter() - t_start
+            if (el >= a.cpu_seconds and len(ts) >= 9) or len(ts) >= 5000:
                 break
+        med = float(np.median(ts))
+        # the other variants of BASELINE.md 4.2 with the same oracle and thread count, median of 9 each
+        res_c = np.zeros(N, np.float32)
+        O.mstep(d0["logits"], d0["labels"], d0["idx"], w0.copy(), res_c, scale_div=N)
+
+        def cpu_estep():
+            O.update_sample_weights(res_c.copy(), np.ones(N, np.float32))
+
+        w_pi = np.ones(N, np.float32)
+        O.update_sample_weights(res_c.copy(), w_pi)
+
+        def cpu_threshold():
+            w_t = w_pi.copy()
+            O.truncate(w_t, O.false_negative_criterion(w_t))
+
+        def cpu_v2():
+            l_b, _ = O.nll_rows(d0["logits"], d0["labels"])
+            pi_b = np.ones(B, np.float32)
+            O.update_sample_weights(l_b, pi_b)
+            O.mstep(d0["logits"], d0["labels"], np.arange(B), pi_b, np.zeros(B, np.float32))
+
+        parts_cpu = {}
+        for name, fn in (("estep_alone_us", cpu_estep), ("threshold_truncate_us", cpu_threshold),
+                         ("in_batch_em_v2_us", cpu_v2)):
+            fn()
+            parts_cpu[name] = median_time(fn, 9) * 1e6
         result["cpu_baseline"] = {
-            "value": n * B / el, "unit": "samples/s", "cores": best_t, "kind": "port",
-            "sample": f"{n} full steps (M-step fwd+bwd + E-step) of the same {B}x{C} workload "
-                      f"in {el:.1f} s; C oracle (oracle/rlvi_oracle.c) with OpenMP on {best_t} "
-                      f"threads (fastest of 1..{ncpu} tried; os.cpu_count()={ncpu})",
+            "value": B / med, "unit": "samples/s", "cores": best_t, "kind": "port",
+            "sample": f"median of {len(ts)} full steps (M-step fwd+bwd + E-step) of the same {B}x{C} workload "
+                      f"({el:.1f} s of CPU work); C oracle (oracle/rlvi_oracle.c) with OpenMP on {best_t} "
+                      f"threads (fastest median of 3 among {sorted(cal)}; os.cpu_count()={ncpu})",
+            "step_us": med * 1e6,
+            "calibration_us": {str(t): (None if v is None else round(v * 1e6, 1)) for t, v in sorted(cal.items())},
+            "parts": {k: round(v, 1) for k, v in parts_cpu.items()},
+            "leg_seconds": round(time.perf_counter() - t_leg, 1),
         }
     if rank == 0:
         print(json.dumps(result))

@@ -63,6 +63,8 @@ def train_rlvi(train_loader, model, optimizer,
     if world > 1:
         rdist.declare_device_sharing()      # (collective once per group, cached afterwards)
     visited, sizes = [], []
+    # the batch loop's launcher, validated once per epoch (vectors, workspace, stream)
+    mstep = ops.MStepLoop(weights, residuals.detach(), ws)
 
     for (images, labels, indexes) in train_loader:
         images = images.to(weights.device, non_blocking=True)
@@ -80,8 +82,7 @@ def train_rlvi(train_loader, model, optimizer,
         # reference :85,:89-94 and the backward of :96 in ONE fused launch over the logits:
         # top-1, per-sample CE, residuals[indexes] = loss, weights[indexes] gather, weighted
         # mean and d(loss)/d(logits); the batch scalars accumulate on the device
-        _, grad = ops.mstep_fwd_bwd(logits.detach(), labels, indexes, weights,
-                                    residuals.detach(), inv_scale=inv_scale, accumulate=True, ws=ws)
+        grad = mstep(logits, labels, indexes, inv_scale)
         train_total += 1
 
         optimizer.zero_grad()

@@ -135,6 +135,56 @@ def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_
     return out, grad
 
 
+class MStepLoop:
+    """mstep_fwd_bwd(..., accumulate=True) for a training loop, validated ONCE: the per-epoch vectors
+    (weights, residuals), the workspace, the stream and the ctypes entry are fixed when the object is made
+    (train_rlvi makes one per epoch), so a batch costs a handful of data_ptr() reads, one cached gradient
+    buffer per batch shape and the foreign call -- the generic wrapper's ~10 checks, dict look-ups,
+    c_void_p objects and current-stream query are what a 4-microsecond kernel at 4096 x 10 was waiting for.
+    A batch that does not look like the validated form (strided / non-fp32-bf16 logits, labels or indexes
+    that are not contiguous int64 device tensors) takes the generic, fully checked path.
+
+    The returned gradient buffer is REUSED by the next batch of the same shape: consume it
+    (`logits.backward(grad)`) before the next call, as train_rlvi does."""
+
+    def __init__(self, weights, residuals, ws=None):
+        L = _lib.load()
+        _require_gpu(weights, residuals)
+        for t in (weights, residuals):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1:
+                raise ValueError("weights / residuals must be contiguous 1-D fp32 tensors")
+        if residuals.shape != weights.shape:
+            raise ValueError("residuals and weights differ in length")
+        self.weights, self.residuals = weights, residuals
+        self.N = weights.shape[0]
+        self.ws = ws or workspace(weights.device, self.N, 0)
+        self._w, self._r, self._wsp = weights.data_ptr(), residuals.data_ptr(), self.ws.buf.data_ptr()
+        self._stream = torch.cuda.current_stream().cuda_stream
+        self._f32, self._bf16 = L.rlvi_mstep_fwd_bwd_f32, L.rlvi_mstep_fwd_bwd_bf16
+        self._grads = {}
+        self._dev = weights.device
+
+    def __call__(self, logits, labels, idx, inv_scale=None):
+        dt = logits.dtype
+        if not (logits.dim() == 2 and (dt is torch.float32 or dt is torch.bfloat16) and logits.is_contiguous()
+                and labels.dtype is torch.int64 and idx.dtype is torch.int64 and labels.is_cuda and idx.is_cuda
+                and logits.is_cuda and labels.is_contiguous() and idx.is_contiguous()):
+            _, grad = mstep_fwd_bwd(logits.detach(), labels, idx, self.weights, self.residuals,
+                                    inv_scale=inv_scale, accumulate=True, ws=self.ws)
+            return grad
+        B, C = logits.shape
+        key = (B, C, dt)
+        grad = self._grads.get(key)
+        if grad is None:
+            grad = self._grads[key] = torch.empty((B, C), dtype=dt, device=self._dev)
+        rc = (self._f32 if dt is torch.float32 else self._bf16)(
+            logits.data_ptr(), C, labels.data_ptr(), idx.data_ptr(), self._w, self._r, self.N, B, C,
+            inv_scale if inv_scale is not None else 1.0 / B, grad.data_ptr(), C, None, self._wsp, self._stream)
+        if rc:
+            _lib.check(rc, "rlvi_mstep_fwd_bwd")
+        return grad
+
+
 def estep_deep(residuals, weights, tol=1e-3, maxiter=40, iters=None, trace=None, ws=None):
     """update_sample_weights (train_rlvi.py:14-38), in place on both vectors."""
     L = _lib.load()

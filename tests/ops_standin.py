@@ -47,6 +47,15 @@ class StandIn:
         ws.acc.append((float(ref["loss"]), float(ref["prec1"])))
         return None, torch.from_numpy(ref["grad"].astype(np.float32))
 
+    def MStepLoop(self, weights, residuals, ws=None):
+        """The per-epoch launcher of the batch loop (rlvi_amd.ops.MStepLoop): same call, oracle arithmetic."""
+        outer = self
+
+        def call(logits, labels, idx, inv_scale=None):
+            return outer.mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=inv_scale,
+                                       accumulate=True, ws=ws or outer.ws)[1]
+        return call
+
     def epoch_end(self, residuals, weights, overfit=False, threshold=0, batches=0, tol=1e-3, maxiter=40,
                   alpha=0.05, out=None, iters=None, ws=None):
         O.update_sample_weights(residuals.numpy(), weights.numpy(), tol=tol, maxiter=maxiter)

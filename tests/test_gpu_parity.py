@@ -267,6 +267,49 @@ def test_estep_threshold_mask_golden(key, golden, gpu, oracle):
     assert dev_status(ops, dev) == 0
 
 
+@pytest.mark.parametrize("key", g1_cases())
+def test_estep_golden_without_trace_takes_the_accept_path(key, golden, gpu, oracle):
+    """The reference's G1 outputs against the path a training run takes: NO error trace (a requested trace
+    switches the acceptance without a verification round off, rlvi_trajb.h) and a WARM workspace -- the
+    call before it ran on a drifted copy of the vector (+2 % and a little noise: what one epoch does to the
+    residuals), so the first round's nodes are the previous call's, a few per cent off, and the stop index
+    comes from the fourth-order chain and the estimated step errors.  Iteration count and pi must be the
+    reference's; then the same call with the verification round forced (RLVI_TJ_VERIFY=1) must agree."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    L = _lib.load()
+    g = golden("g1_g2_estep_threshold")
+    r, w, N = g1_inputs(g, key, oracle)
+    sl = slice(None, None, int(g["stride"])) if N > 4096 else slice(None)
+    rng = np.random.default_rng(N)
+    drift = (r * np.float32(1.02) + np.float32(0.01) * rng.random(N).astype(np.float32)).astype(np.float32)
+    got = {}
+    for verify in (0, 1):
+        _lib.check(L.rlvi_tune_set(b"RLVI_TJ_VERIFY", verify), "tune")
+        try:
+            ws = ops.Workspace(dev, N, 0)
+            ops.estep_deep(torch.from_numpy(drift.copy()).to(dev), torch.ones(N, device=dev), ws=ws)   # warms the state
+            rt = torch.from_numpy(r.copy()).to(dev)
+            wt = torch.from_numpy(w.copy()).to(dev)
+            iters = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.estep_deep(rt, wt, iters=iters, ws=ws)
+            torch.cuda.synchronize()
+            assert ws.status() == 0
+            got[verify] = (int(iters), wt.cpu().numpy(), rt.cpu().numpy())
+        finally:
+            _lib.check(L.rlvi_tune_set(b"RLVI_TJ_VERIFY", 0), "tune")
+    for verify in (0, 1):
+        it, wo, ro = got[verify]
+        assert it == int(g[key + "/iters"]), (verify, it)
+        rel, small = rel_pi(wo[sl], g[key + "/w_out"])
+        assert rel <= REL and small <= 1e-7, verify
+        assert np.array_equal(ro[sl], g[key + "/res_out"])
+    # with and without the shortcut: the same fixed point to the accepted node error (1e-6 relative)
+    a, b = got[0][1].astype(np.float64), got[1][1].astype(np.float64)
+    big = b >= 1e-6 * b.max()
+    assert np.max(np.abs(a[big] - b[big]) / b[big]) <= 4e-6
+
+
 def test_threshold_handmade_and_standalone(golden, gpu):
     torch, ops, dev = gpu
     g = golden("g1_g2_estep_threshold")
@@ -440,6 +483,57 @@ def test_estep_random_walk_of_inputs_on_one_workspace(N, gpu, oracle):
         assert np.array_equal(rt.cpu().numpy(), rr)
 
 
+@pytest.mark.parametrize("N", [8192, 65536, 200000])
+def test_estep_drifting_inputs_with_and_without_the_accept_shortcut(N, gpu, oracle):
+    """What a training run feeds the E-step: every call's losses are the previous call's, drifted (scaled
+    by a few per cent, shifted, with new noise, the clean / noisy mix changing slowly).  Two workspaces run
+    the same randomised sequence of 16 vectors -- one accepts the first round on its fourth-order chain and
+    estimated step errors where its bands allow it (the default), the other is forced to verify
+    (RLVI_TJ_VERIFY=1).  Every call: the same iteration count and the same pi (to the accepted node error)
+    on both, and the oracle's iteration count whenever the oracle's stop test is not a near-tie."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(77 + N)
+    ws_a, ws_v = ops.Workspace(dev, N, 0), ops.Workspace(dev, N, 0)
+    clean = rng.random(N) < 0.55
+    base = rng.exponential(0.05, N)
+    base[~clean] += 12.0 + rng.standard_normal(int((~clean).sum()))
+    r = base.astype(np.float32)
+    for trial in range(16):
+        # drift: scale 0.93 .. 1.07, a shift, fresh per-sample noise, and 1 % of the samples change sides
+        flip = rng.random(N) < 0.01
+        r = r * np.float32(rng.uniform(0.93, 1.07)) + np.float32(rng.uniform(0.0, 0.05))
+        r = r + (0.02 * rng.standard_normal(N)).astype(np.float32) * (r > 1.0)
+        r[flip] = np.where(r[flip] > 6.0, rng.exponential(0.05, int(flip.sum())),
+                           12.0 + rng.standard_normal(int(flip.sum()))).astype(np.float32)
+        r = np.abs(r).astype(np.float32)
+        w0 = rng.random(N).astype(np.float32) if trial % 3 == 0 else np.ones(N, np.float32)
+        rr, ww = r.copy(), w0.copy()
+        it, err, _ = oracle.update_sample_weights(rr, ww, trace=True)
+        out = []
+        for verify, ws in ((0, ws_a), (1, ws_v)):
+            _lib.check(L.rlvi_tune_set(b"RLVI_TJ_VERIFY", verify), "tune")
+            try:
+                rt, wt = torch.from_numpy(r.copy()).to(dev), torch.from_numpy(w0.copy()).to(dev)
+                iters = torch.zeros(1, dtype=torch.int32, device=dev)
+                ops.estep_deep(rt, wt, iters=iters, ws=ws)
+                torch.cuda.synchronize()
+                assert ws.status() == 0, (trial, verify)
+                out.append((int(iters), wt.cpu().numpy()))
+            finally:
+                _lib.check(L.rlvi_tune_set(b"RLVI_TJ_VERIFY", 0), "tune")
+        assert out[0][0] == out[1][0], (trial, out[0][0], out[1][0], it)
+        if np.min(np.abs(err - 1e-3)) >= 1e-4 * 1e-3:
+            assert out[0][0] == it, (trial, out[0][0], it)
+        for _, wg in out:
+            rel, small = rel_pi(wg, ww)
+            assert rel <= REL and small <= 1e-7, trial
+        a, b = out[0][1].astype(np.float64), out[1][1].astype(np.float64)
+        big = b >= 1e-6 * b.max()
+        assert np.max(np.abs(a[big] - b[big]) / b[big]) <= 4e-6, trial
+
+
 @pytest.mark.parametrize("N", [65536, 524288])
 def test_cooperative_kernels_under_concurrent_load(N, gpu, oracle):
     """The cooperative E-step and threshold kernels need their ~240 workgroups co-resident.  With
@@ -576,9 +670,12 @@ def test_fused_em_matches_composition(B, C, gpu, oracle):
     rel, small = rel_pi(pit.cpu().numpy(), w2)
     assert rel <= REL and small <= 1e-7
     np.testing.assert_allclose(rows.cpu().numpy(), l2, rtol=REL, atol=1e-6)
-    assert abs(float(out[0]) - float(ref["loss"])) <= 2 * REL * abs(float(ref["loss"]))
+    # north_star's bar for the fused E+M: pi and the weighted loss within 1e-5 of the reference path
+    loss_rel = abs(float(out[0]) - float(ref["loss"])) / abs(float(ref["loss"]))
+    assert loss_rel <= REL, loss_rel
     diff = grad.cpu().numpy().astype(np.float64) - ref["grad"]
-    assert np.sqrt((diff ** 2).sum()) <= 2 * REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+    grad_rel = np.sqrt((diff ** 2).sum()) / np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+    assert grad_rel <= REL, grad_rel
 
 
 def _fused_em_run(ops, torch, dev, d, pi0, ws, fused, maxiter=40):
@@ -758,6 +855,47 @@ def test_linreg_and_logistic_nll(gpu, oracle):
     ref = oracle.logistic_nll(Xl, wl, b)
     got = ops.logistic_nll(torch.from_numpy(Xl).to(dev), torch.from_numpy(wl).to(dev), b)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("n,d", [(256, 561), (4096, 561), (100, 128), (33, 130), (17, 1000), (16, 127), (1, 129),
+                                 (257, 124)])
+def test_logistic_nll_long_rows_split_over_the_waves(n, d, gpu, oracle):
+    """X.w for rows of 128 columns and more (HAR's 561 features): one workgroup per 16-row block, its four
+    waves take a quarter of the columns each (aux.hip, logistic_nll_splitk_kernel) -- ragged last quarter,
+    row counts that are not a multiple of 16, a last block of one row; d = 124 / 127 stay on the
+    one-wave-per-block kernel whose k-loop takes four panels per trip (tail of 3 panels / 3 columns)."""
+    torch, ops, dev = gpu
+    Xl, wl, b = synth.logistic_data(n, d, seed=n + d)
+    ref = oracle.logistic_nll(Xl, wl, b)
+    got = ops.logistic_nll(torch.from_numpy(Xl).to(dev), torch.from_numpy(wl).to(dev), b)
+    torch.cuda.synchronize()
+    # (the four partial products are added in wave order: not the oracle's left-to-right sum, so the last
+    #  bits of x.w differ -- 1e-16 * sqrt(d) on a sum of size 1)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-11, atol=1e-14)
+    # a large margin on both sides: -log sigmoid(z) = softplus(-z) must neither overflow nor lose the tail
+    big = np.zeros(d)
+    big[0] = 1.0
+    Xb = np.zeros((n, d))
+    Xb[:, 0] = np.linspace(-800.0, 800.0, n)
+    refb = oracle.logistic_nll(Xb, big, 0.0)
+    gotb = ops.logistic_nll(torch.from_numpy(Xb).to(dev), torch.from_numpy(big).to(dev), 0.0)
+    np.testing.assert_allclose(gotb.cpu().numpy(), refb, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("n,d", [(1000, 63), (1000, 17), (77, 5), (16, 61), (4099, 33)])
+def test_linreg_losses_column_tails(n, d, gpu, oracle):
+    """X.theta on the fp64 matrix cores with column counts that are not a multiple of the 16-column trip of
+    the k-loop (four 4-column panels per trip): 63 = 3 trips + 3 panels + 3 columns, 17 = 1 trip + 1 column,
+    5, 61, 33; row counts that are not a multiple of 16."""
+    torch, ops, dev = gpu
+    X, y = synth.linreg_data(n, d, seed=d)
+    rng = np.random.default_rng(n)
+    theta = 1 + 0.1 * rng.standard_normal(d)
+    w = rng.random(n)
+    ref, s2 = oracle.linreg_losses(X, y, theta, w)
+    got, s2g = ops.linreg_losses(*(torch.from_numpy(a).to(dev) for a in (X, y, theta, w)))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-10)
+    assert float(s2g) == pytest.approx(s2, rel=1e-11)
 
 
 def test_standard_and_online_mirrors_golden(golden, gpu, oracle):
@@ -1029,7 +1167,7 @@ def test_bench_two_ranks_on_one_gpu(mode, gpu):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "6", "--warmup", "2", "--rows", "32768", "--backend", "gloo",
-                        "--same-device", "--no-cpu-baseline", "--estep-dist", mode], capture_output=True,
+                        "--same-device", "--no-cpu-baseline", "--no-epoch-legs", "--estep-dist", mode], capture_output=True,
                        text=True, timeout=300,
                        env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -1052,8 +1190,8 @@ def _run_bench(args, timeout=400, env_extra=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra or {})
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
-                       timeout=timeout, env=env, cwd=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--no-epoch-legs"],
+                       capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     return p, [json.loads(ln) for ln in lines]
 
@@ -1117,6 +1255,12 @@ def test_bench_absent_peer_lands_on_the_replicated_path_in_bounded_time(gpu):
     assert res["value"] > 0
 
 
+def oracle_pi(oracle, r):
+    rr, ww = r.copy(), np.ones(r.shape[0], np.float32)
+    oracle.update_sample_weights(rr, ww)
+    return ww
+
+
 def test_epoch_end_with_truncation_is_graph_capturable(gpu, oracle):
     """E-step + type-II threshold + truncation (train_rlvi.py:99-103) captured in ONE hipGraph and
     replayed on fresh data: no host synchronisation, no allocation the capture cannot hold, same
@@ -1131,12 +1275,14 @@ def test_epoch_end_with_truncation_is_graph_capturable(gpu, oracle):
     mask = torch.empty(N, dtype=torch.uint8, device=dev)
     kept = torch.zeros(1, dtype=torch.int64, device=dev)
     iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    pi_gpu = torch.empty(N, device=dev)
     L = __import__("rlvi_amd._lib", fromlist=["load"]).load()
     side = torch.cuda.Stream()
 
     def enqueue():
         st = ops._stream_ptr()
         assert L.rlvi_estep_deep_f32(ops._ptr(res), ops._ptr(wts), N, 1e-3, 40, ops._ptr(iters), None, ws.ptr, st) == 0
+        pi_gpu.copy_(wts)        # (captured too: the E-step's own pi, before the truncation zeroes part of it)
         assert L.rlvi_threshold_truncate_f32(ops._ptr(wts), N, 0.05, ops._ptr(thr), ops._ptr(mask),
                                              ops._ptr(kept), ws.ptr, st) == 0
 
@@ -1157,12 +1303,21 @@ def test_epoch_end_with_truncation_is_graph_capturable(gpu, oracle):
             t_ref = oracle.false_negative_criterion(ww)
             m_ref = oracle.truncate(ww, t_ref)
             assert ws.status() == 0 and int(iters) == it
-            # the threshold is taken on the GPU's own pi (a few 1e-7 from the oracle's), so it is the
-            # oracle's up to that, and so is the number of samples on the other side of it
+            # pi itself: the oracle's to 1e-5
+            pg = pi_gpu.cpu().numpy()
+            rel, small = rel_pi(pg, oracle_pi(oracle, r))
+            assert rel <= REL and small <= 1e-7
+            # threshold, truncation, mask and kept count: the oracle's ON THE GPU'S OWN PI, bit for bit
+            # (the selection is integer work once pi is given; against the oracle's pi the threshold is
+            #  the same up to pi's 1e-7 and a sample next to it may fall on the other side)
+            t_gpu = oracle.false_negative_criterion(pg)
+            w_gpu = pg.copy()
+            m_gpu = oracle.truncate(w_gpu, t_gpu)
+            assert float(thr) == float(t_gpu)
+            assert int(kept) == int(m_gpu.sum())
+            assert np.array_equal(np.packbits(mask.cpu().numpy()), np.packbits(m_gpu))
+            assert np.array_equal(wts.cpu().numpy(), w_gpu)
             assert abs(float(thr) - float(t_ref)) <= 1e-5 * max(float(t_ref), 1e-30)
-            assert abs(int(kept) - int(m_ref.sum())) <= 2
-            got = wts.cpu().numpy()
-            assert np.array_equal(mask.cpu().numpy().astype(bool), got > float(thr))
 
 
 # ------------------------------------------------------------------------------ two ranks, one GPU
@@ -1432,34 +1587,67 @@ def test_train_rlvi_owner_sharded_epoch_end_needs_no_collective(gpu):
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in results), [r[1] for r in results]
-    # one process, the same global batches
+    # one process, the same global batches: the product path in fp32 and, to size the tolerance, the same
+    # epochs as a plain-torch restatement in fp64 (as G4 does with the reference itself): how far the
+    # single-device fp32 run drifts from exact arithmetic is the yardstick for how far a different -- but
+    # equally valid -- fp32 evaluation order (half batches, DDP's gradient averaging, the sharded E-step's
+    # partial sums) may land from it.  Accepted: G4's rule, 16 x that drift plus one fp32 ulp of the largest value.
     X, y = _owner_data(N, D, C)
     Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
     torch.manual_seed(7)
     model = torch.nn.Linear(D, C).to(dev)
+    model64 = torch.nn.Linear(D, C).to(dev).double()
+    with torch.no_grad():
+        for p64, p32 in zip(model64.parameters(), model.parameters()):
+            p64.copy_(p32.double())
     opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    opt64 = torch.optim.SGD(model64.parameters(), lr=0.5)
     residuals, weights = torch.zeros(N, device=dev), torch.ones(N, device=dev)
-    thr = 0.0
+    res64, w64 = torch.zeros(N, device=dev, dtype=torch.float64), torch.ones(N, device=dev, dtype=torch.float64)
+    thr, thr64 = 0.0, 0.0
+    MULT = 16.0
+
+    def tol_of(a32, a64):
+        return MULT * float(np.abs(a32 - a64).max()) + 1.2e-7 * float(np.abs(a32).max())
+
     for ep in range(epochs):
         per = [_owner_batches(r, world, N, per_rank, ep) for r in range(world)]
-        loader = []
+        loader, loader64 = [], []
         for b in range(len(per[0])):
             ix = np.concatenate([per[r][b] for r in range(world)])
-            loader.append((Xd[ix], yd[ix], torch.from_numpy(ix).to(dev)))
+            ixt = torch.from_numpy(ix).to(dev)
+            loader.append((Xd[ix], yd[ix], ixt))
+            loader64.append((Xd[ix].double(), yd[ix], ixt))
         acc, thr = train_rlvi(loader, model, opt, residuals, weights, ep >= 1, thr)
+        _, thr64 = _eager_train_rlvi(loader64, model64, opt64, res64, w64, ep >= 1, thr64, estep="torch")
+        w_all, r_all = weights.cpu().numpy(), residuals.cpu().numpy()
+        w_all64, r_all64 = w64.cpu().numpy(), res64.cpu().numpy()
+        # (a weight next to the threshold may be truncated in one run and not in the other: such entries
+        #  are compared through their distance to the threshold, not as 0 against pi)
+        same_side = (w_all == 0) == (w_all64 == 0)
+        tol_w = tol_of(w_all[same_side], w_all64[same_side])
+        tol_r = tol_of(r_all, r_all64)
+        tol_t = MULT * max(abs(float(thr) - float(thr64)), tol_w / MULT) + 1.2e-7
         for r in range(world):
             acc_r, thr_r, w_r, res_r = results[r][2][ep]
             own = np.arange(r, N, world)
-            assert abs(acc_r - acc) <= 0.02, (ep, acc_r, acc)
-            assert abs(thr_r - float(thr)) <= 2e-4 * max(abs(float(thr)), 1e-3), (ep, thr_r, float(thr))
-            w1 = weights.cpu().numpy()[own]
-            trunc_differs = (w_r == 0) != (w1 == 0)            # (a weight within rounding of the threshold)
-            assert trunc_differs.mean() <= 1e-3
-            np.testing.assert_allclose(w_r[~trunc_differs], w1[~trunc_differs], rtol=2e-3, atol=2e-6)
-            np.testing.assert_allclose(res_r, residuals.cpu().numpy()[own], rtol=2e-3, atol=2e-5)
+            assert abs(acc_r - acc) <= 100.0 * 2 / N + 1e-4, (ep, acc_r, acc)     # (a near-tied arg-max or two)
+            assert abs(thr_r - float(thr)) <= tol_t, (ep, thr_r, float(thr), tol_t)
+            w1 = w_all[own]
+            trunc_differs = (w_r == 0) != (w1 == 0)
+            if trunc_differs.any():
+                near = np.maximum(w_r[trunc_differs], w1[trunc_differs])            # the untruncated one of the pair
+                assert np.all(np.abs(near - float(thr)) <= tol_t + tol_w), (ep, near, float(thr))
+            err_w = float(np.abs(w_r[~trunc_differs] - w1[~trunc_differs]).max())
+            assert err_w <= tol_w, (ep, "weights", err_w, tol_w)
+            err_r = float(np.abs(res_r - r_all[own]).max())
+            assert err_r <= tol_r, (ep, "residuals", err_r, tol_r)
     params = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu().numpy()
+    params64 = torch.cat([p.detach().flatten() for p in model64.parameters()]).cpu().numpy()
+    tol_p = tol_of(params, params64)
     for r in range(world):
-        np.testing.assert_allclose(results[r][3], params, rtol=2e-3, atol=2e-5)
+        err_p = float(np.abs(results[r][3] - params).max())
+        assert err_p <= tol_p, ("params", err_p, tol_p)
 
 
 def test_sharded_estep_refuses_a_workspace_without_a_peer_table(gpu):
@@ -1528,9 +1716,13 @@ def test_top1_on_tied_maxima_golden(key, dtype, golden, gpu):
 
 
 # ------------------------------------------------------------------------------ driver at cfg3 size
-def _eager_train_rlvi(train_loader, model, optimizer, residuals, weights, overfit, threshold):
-    """The statements of the reference's epoch (train_rlvi.py:52-106) with stock torch ops on the
-    device -- the checker for the driver's bookkeeping, not a product path."""
+def _eager_train_rlvi(train_loader, model, optimizer, residuals, weights, overfit, threshold, estep="oracle"):
+    """The reference's epoch (train_rlvi.py:52-106) as a checker, not a product path: the batch loop is
+    the reference's own stock torch calls (:85-97: softmax / argmax, F.cross_entropy, index put / gather,
+    mean, autograd, optimizer); the epoch end (:99-103: update_sample_weights, false_negative_criterion,
+    truncation) goes through the PINNED C oracle (oracle/rlvi_oracle.c, held to the reference's own outputs
+    by tests/test_oracle_golden.py).  estep="torch": the epoch end as torch statements in the dtype of
+    `weights` instead -- only used in fp64, to measure how far an fp32 run drifts from exact arithmetic."""
     import torch
     import torch.nn.functional as F
     dev = weights.device
@@ -1547,6 +1739,20 @@ def _eager_train_rlvi(train_loader, model, optimizer, residuals, weights, overfi
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
+    if estep == "oracle":
+        from oracle import rlvi_oracle as O
+        O.build()
+        r = residuals.detach().cpu().numpy().astype(np.float32)
+        w = weights.detach().cpu().numpy().astype(np.float32)
+        O.update_sample_weights(r, w)                                        # :99  (:14-38)
+        if overfit:
+            threshold = max(np.float32(float(threshold)), O.false_negative_criterion(w))   # :101-102 (:41-49)
+            O.truncate(w, threshold)                                         # :103
+            threshold = torch.tensor(float(threshold), device=dev)
+        with torch.no_grad():
+            residuals.copy_(torch.from_numpy(r))
+            weights.copy_(torch.from_numpy(w))
+        return correct / total, threshold
     with torch.no_grad():
         residuals.sub_(residuals.min())
         e = torch.exp(-residuals)
