@@ -29,8 +29,10 @@
 
 namespace rlvi {
 
+// (one-sample slices at 256 threads: three waves per SIMD -- at most 168 registers -- so that the occupancy
+//  query proves 512 workgroups co-resident and the full 256 + 1 grid keeps its one-sample slices)
 template <int E, int TB_BLOCK>
-__global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
+__global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMPS) ? 3 : 1) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
     float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G,
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(TB_BLOCK) void estep_trajb_kernel(
         reduce_partials(part, MSTEP_MAX_BLOCKS, mstep_scale, mstep_out, true, TB_BLOCK);
         return;
     }
-    __shared__ TbShared<TB_BLOCK / WAVE> sh;
+    __shared__ TbShared<TB_BLOCK / WAVE, tb_stage(E, TB_BLOCK)> sh;
     const int tid = threadIdx.x;
     const int b = (int)blockIdx.x;
     const int64_t L = (N + G - 1) / G;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     constexpr int NI = KMAX;                                      // 1-KiB pieces per tile (max)
     constexpr int WTILE = NI * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [FE_WAVES][FE_TPW][WTILE]
-    __shared__ TbShared<FE_EB / WAVE> sh;
+    __shared__ TbShared<FE_EB / WAVE, tb_stage(1, FE_EB)> sh;
     __shared__ float nll[FE_ROWS];
     __shared__ FeRow rowinfo[FE_WAVES][FE_TPW][FE_R];
     __shared__ double red[2 * FE_WAVES];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
 
     // RLVI_TJ_DEBUG: wall-clock stamps (100 MHz) of workgroup 0's phases, behind the solve's own
-#define FE_STAMP(k) do { if (dbg != nullptr && b == 0 && tid == 0) dbg[970 + (k)] = wall_clock64(); } while (0)
+#define FE_STAMP(k) do { if ((RLVI_STAMPS && dbg != nullptr) && b == 0 && tid == 0) dbg[970 + (k)] = wall_clock64(); } while (0)
     FE_STAMP(0);
     const int64_t wg_row0 = (int64_t)b * FE_ROWS;
     const int64_t wrow0 = wg_row0 + (int64_t)wave * FE_TPW * FE_R;

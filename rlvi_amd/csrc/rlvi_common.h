@@ -8,6 +8,14 @@
 
 #include "rlvi_hip.h"
 
+// In-kernel wall-clock stamps and value dumps of the cooperating kernels (RLVI_TJ_DEBUG / RLVI_THR_DEBUG
+// at run time) exist only in a -DRLVI_STAMPS=1 build (tools/build_variants.py stamps; load it with
+// RLVI_LIB_PATH): in the product build they are compiled out -- the stamp pointer, its counter and the
+// guards around every dump cost the trajectory kernels some twenty registers, i.e. a wave per SIMD.
+#ifndef RLVI_STAMPS
+#define RLVI_STAMPS 0
+#endif
+
 namespace rlvi {
 
 constexpr int WAVE = 64;

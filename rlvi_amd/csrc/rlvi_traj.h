@@ -27,6 +27,11 @@ struct TjOut {
     int res_it;
     int res_found;               // a stop index was found among the evaluated nodes (or Ke == Ka)
     float res_delta, res_rfin, res_min;
+    // per-node coefficients of the serial chain, written by the node's lane and read back by ALL lanes one
+    // node at a time (an LDS broadcast read: two 16-byte reads per step, asked for one step ahead, instead
+    // of six v_readlane whose SGPR results each cost the wave wait states before a vector instruction may
+    // use them): {r', a0, b, c, R3, R4, -, -}
+    alignas(16) float coef[TJ_MAXK + 1][8];
 };
 
 // Neighbour lanes and an affine scan over the 64 lanes without the LDS crossbar (a __shfl is a
@@ -104,7 +109,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     const int lane = threadIdx.x & (WAVE - 1);
     const bool has = lane < Ke;
     // RLVI_TJ_DEBUG: where the recurrence wave's time goes (first round of workgroup 0)
-#define TJ_STAMP(k) do { if (dbg != nullptr && blockIdx.x == 0 && xstep == 0 && lane == 0) dbg[990 + (k)] = wall_clock64(); } while (0)
+#define TJ_STAMP(k) do { if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep == 0 && lane == 0) dbg[990 + (k)] = wall_clock64(); } while (0)
     TJ_STAMP(0);
     float scale = 1.0f;
     if (FIRST) {
@@ -121,7 +126,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
                       : true;
     if (HI && has) finite = finite && tR3 == tR3 && tR4 == tR4 && tR3 < 1e300 && tR4 < 1e300;
     const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
-    if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+    if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep == 0) {
         if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tQ); }
         if (lane == 0) { dbg[102] = __ballot(finite); dbg[103] = __float_as_uint(scale); }
     }
@@ -184,29 +189,45 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     //  Estrin pair -> avg -> 1 - avg -> rcp -> next dr; the six v_readlane of a step already issue in its
     //  stalls -- writing four steps per loop iteration side by side changed nothing.)
     if (!scanned) {
-#pragma unroll 1
-        for (int step = 0; step < steps; ++step) {
-            const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
-            const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
-            const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
-            const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_l), step));
-            if (lane == step) rnew_l = r;
-            const float dr = r - rns;
-            float avg;
-            if (HI) {
-                // S(r' + d) = S + S' d - Q d^2 + R3 d^3 - R4 d^4 + ...  (alternating for d > 0, terms
-                // falling by a factor <= |d|/r')
-                const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r3_l), step));
-                const float r4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r4_l), step));
-                // (Estrin: three dependent levels behind dr instead of four)
-                const float dr2 = dr * dr;
-                const float lo2 = fmaf(dr, bb, a0), hi2 = fmaf(dr, r3, -cc);
-                avg = fmaf(dr2 * dr2, -r4, fmaf(dr2, hi2, lo2));
-            } else {
-                avg = fmaf(dr, fmaf(-cc, dr, bb), a0);
+        if (HI) {
+            // Fourth-order chain.  S(r' + d) = S + S' d - Q d^2 + R3 d^3 - R4 d^4 + ...  (alternating for
+            // d > 0, terms falling by a factor <= |d|/r').  The arithmetic of a step is what it always was
+            // (Estrin: three dependent levels behind dr); its six per-node operands now come through LDS.
+            {
+                float *cf = out.coef[lane];
+                *reinterpret_cast<float4 *>(cf) = make_float4(rn, a0_l, b_l, c_l);
+                *reinterpret_cast<float2 *>(cf + 4) = make_float2(r3_l, r4_l);
+                if (lane == 0) *reinterpret_cast<float4 *>(out.coef[TJ_MAXK]) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
             }
-            if (lane == step) avg_l = avg;
-            r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
+            __builtin_amdgcn_wave_barrier();
+            float4 ca = *reinterpret_cast<const float4 *>(out.coef[0]);
+            float2 cb = *reinterpret_cast<const float2 *>(out.coef[0] + 4);
+#pragma unroll 1
+            for (int step = 0; step < steps; ++step) {
+                const float4 na = *reinterpret_cast<const float4 *>(out.coef[step + 1]);     // (one step ahead)
+                const float2 nb = *reinterpret_cast<const float2 *>(out.coef[step + 1] + 4);
+                if (lane == step) rnew_l = r;
+                const float dr = r - ca.x;
+                const float dr2 = dr * dr;
+                const float lo2 = fmaf(dr, ca.z, ca.y), hi2 = fmaf(dr, cb.x, -ca.w);
+                const float avg = fmaf(dr2 * dr2, -cb.y, fmaf(dr2, hi2, lo2));
+                if (lane == step) avg_l = avg;
+                r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
+                ca = na; cb = nb;
+            }
+        } else {
+#pragma unroll 1
+            for (int step = 0; step < steps; ++step) {
+                const float rns = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), step));
+                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0_l), step));
+                const float bb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), step));
+                const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_l), step));
+                if (lane == step) rnew_l = r;
+                const float dr = r - rns;
+                const float avg = fmaf(dr, fmaf(-cc, dr, bb), a0);
+                if (lane == step) avg_l = avg;
+                r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
+            }
         }
     }
     TJ_STAMP(2);   // serial chain done
@@ -321,7 +342,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         const bool act = live && lane + 1 < steps;
         float of = act ? rem * iom2 * irn : 0.0f;                            // rho_k
         float sc = act ? fminf(fabsf(b_l) * rnew_l * iom2 * irn, 1.0f) : 0.0f;   // s_k
-        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0)
+        if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep == 0)
             dbg[828 + lane] = ((unsigned long long)__float_as_uint(sc) << 32) | __float_as_uint(of);
         affine_scan(sc, of);                                                 // x -> sc x + of, inclusive
         float Ek = lane_up1(of);                                             // bound on |r_k - true| / r_k
@@ -366,7 +387,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
             const unsigned long long upto = ks >= 63 ? ~0ull : ((2ull << ks) - 1ull);
             if ((unclear & upto) == 0ull && ks + 1 <= steps) { accept_now = true; it_acc = ks + 1; }
         }
-        if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+        if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep == 0) {
             dbg[700 + lane] = ((unsigned long long)__float_as_uint(err_e) << 32) | __float_as_uint(band);
             dbg[764 + lane] = ((unsigned long long)__float_as_uint(Ek) << 32) | __float_as_uint(slope);
             if (lane == 0) dbg[699] = ((unsigned long long)(accept_now ? 1 : 0) << 32) | (unsigned)it_acc;
@@ -389,9 +410,9 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
         const bool unsafe = has && lane < it_now && fabsf(err_l - tol) <= u * err_l;
         if (__ballot(unsafe) == 0ull) delta_w = 0.0f;
     }
-    if (dbg != nullptr && blockIdx.x == 0 && xstep < 4)
+    if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep < 4)
         dbg[400 + xstep * 64 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
-    if (dbg != nullptr && blockIdx.x == 0 && xstep == 0) {
+    if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep == 0) {
         dbg[130 + lane] = ((unsigned long long)__float_as_uint(rn) << 32) | __float_as_uint(rnew_l);
         if (lane == 0) { dbg[128] = round_ok; dbg[129] = ((unsigned long long)it_now << 32) | __float_as_uint(delta_w); }
     }

@@ -27,12 +27,21 @@ constexpr int TB_CHUNK = 8;
 constexpr int TB_NV = 8;             // values of a record: {S, P, Q, D, min, R3, R4, -}
 constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
 
-template <int TB_NW>
+// Node-split sums (slices up to TB_NSPLIT_MAXE samples per thread): the slice's e = exp(-(l - min)) and
+// the caller's pi are staged through LDS so that EVERY wave sees all samples and the waves share out the
+// NODES instead of the samples (see `sums_split` below).
+constexpr int TB_NSPLIT_MAXS = 1024;     // node-split up to this many samples per workgroup (16 per lane)
+constexpr bool tb_nsplit(int E, int block) { return E * block <= TB_NSPLIT_MAXS; }
+constexpr int tb_stage(int E, int block) { return tb_nsplit(E, block) ? E * block : 4; }
+
+template <int TB_NW, int STAGE = 4>
 struct TbShared {
-    float wp[TB_NW][TJ_MAXK][8];     // wave partials {S, P, Q, D, R3, R4, P2, -} per node
+    float wp[TB_NW][TJ_MAXK][8];     // wave partials {S, P, Q, D, R3, R4, P2, -} per node ([0] alone: node-split)
     float pmin[TB_NW];
     double red[TB_PER][TB_NV];
     TjOut out;
+    alignas(16) float es[STAGE];     // e of every sample of the slice (node-split sums)
+    alignas(16) float qs[STAGE];     // the caller's pi of every sample (D_0)
 };
 
 // v[q]: this lane's partial of node q of a chunk.  Returns, in lane l, the wave total of node
@@ -157,12 +166,12 @@ __device__ __forceinline__ float tb_weight(const TbSolved &s, float pmax, float 
 // Workgroup b of G.
 template <int E, int TB_BLOCK, int NGRP = 1>
 __device__ __forceinline__ TbSolved trajb_solve(
-    TbShared<TB_BLOCK / WAVE> &sh, const TbWarm &wm, const float (&l)[E], const float (&q0)[E],
+    TbShared<TB_BLOCK / WAVE, tb_stage(E, TB_BLOCK)> &sh, const TbWarm &wm, const float (&l)[E], const float (&q0)[E],
     float (&ev)[E], const bool active, const int b, const int G, const int64_t N, const float tol,
     const int K, int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
     unsigned long long *__restrict__ dbg, PeerTable *__restrict__ pt = nullptr, const bool verify = false) {
     int dbgi = 0;
-#define TB_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
+#define TB_STAMP() do { if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
     TB_STAMP();
     constexpr int TB_NW = TB_BLOCK / WAVE;
     static_assert(TB_NW >= TB_PER, "the stage-A gather needs four waves");
@@ -195,7 +204,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
     const float shift = wm.shift;
     float rn_l = wm.rn_l;
     auto round8 = [K](int v) { v = (v + TB_CHUNK - 1) / TB_CHUNK * TB_CHUNK; return v < K ? v : K; };
-    int Ke = wm.warm ? round8(wm.it + 2) : K;            // evaluated nodes
+    int Ke = __builtin_amdgcn_readfirstlane(wm.warm ? round8(wm.it + 2) : K);            // evaluated nodes (uniform)
 
     // ---- the slice is in registers (pads: l = +inf, q0 = 0): e' and the local minimum
     float mn = __builtin_inff();
@@ -205,6 +214,29 @@ __device__ __forceinline__ TbSolved trajb_solve(
     for (int j = 0; j < E; ++j) ev[j] = expf(-(l[j] - shift));      // pads: exp(-inf) = 0
     mn = group_allreduce<WAVE>(mn, FMin());
     if (lane == 0 && active && sgrp == 0) sh.pmin[wave] = mn;
+    // Node-split sums: with few samples per thread the per-node sums are not arithmetic but the
+    // transposing butterflies -- a fixed cost per WAVE and node chunk (19 cross-lane operations per
+    // quantity and 8 nodes), paid by every wave for all nodes.  So the slice goes through LDS once, every
+    // lane takes SPL = 4 E consecutive samples of the WHOLE slice, and the waves share out the nodes: wave w
+    // takes nodes [w npw, (w + 1) npw), npw = ceil(Ke / waves) -- a quarter of the butterflies per wave (an
+    // eighth with the in-batch kernel's eight waves), the same arithmetic per lane, sample pairs in packed
+    // fp32 even at one sample per thread, and a node's totals come out of ONE wave (no cross-wave sum).
+    constexpr bool NSPLIT = tb_nsplit(E, TB_BLOCK);
+    constexpr int SPL = NSPLIT ? E * TB_BLOCK / WAVE : 4;      // samples per lane
+    constexpr int NWS = NGRP * (TB_BLOCK / WAVE);              // waves that share out the nodes
+    auto stage_slice = [&](bool with_q) {
+        if constexpr (NSPLIT) {
+            if (active && sgrp == 0) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    sh.es[tid + j * TB_BLOCK] = ev[j];
+                    if (with_q) sh.qs[tid + j * TB_BLOCK] = q0[j];
+                }
+            }
+            __syncthreads();
+        }
+    };
+    stage_slice(true);
     TB_STAMP();   // slice loaded
 
     const float invN = 1.0f / (float)N;
@@ -305,12 +337,102 @@ __device__ __forceinline__ TbSolved trajb_solve(
         };
         // (only the 256-thread geometry, i.e. slices up to 8192 samples: the fat 512-thread forms have
         //  no registers to spare for three more accumulator sets)
+        auto sums_split = [&](auto hi_tag) {
+            // (no implicit contraction in here: which a * b + c the compiler fuses may differ between the
+            //  kernels this is inlined into and between the two places that evaluate pi at a node -- the
+            //  stand-alone E-step and the in-batch kernel must produce the same bits from the same slice)
+#pragma clang fp contract(off)
+            constexpr bool HI = decltype(hi_tag)::value;
+            const int npw = (Ke + NWS - 1) / NWS;
+            // (wave-uniform, and told so: the node loop's bounds and the lane selects below stay scalar)
+            const int n0 = __builtin_amdgcn_readfirstlane(wave * npw);   // this wave's nodes [n0, n1)
+            const int n1 = __builtin_amdgcn_readfirstlane(n0 + npw < Ke ? n0 + npw : Ke);
+            if (n0 >= n1) return;
+            float e4[SPL], fpv[SPL];
+#pragma unroll
+            for (int s4 = 0; s4 < SPL; s4 += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&sh.es[lane * SPL + s4]);
+                e4[s4] = v.x; e4[s4 + 1] = v.y; e4[s4 + 2] = v.z; e4[s4 + 3] = v.w;
+            }
+            if (n0 == 0) {                                     // "node -1" = the caller's pi (D_0)
+#pragma unroll
+                for (int s4 = 0; s4 < SPL; s4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&sh.qs[lane * SPL + s4]);
+                    fpv[s4] = v.x; fpv[s4 + 1] = v.y; fpv[s4 + 2] = v.z; fpv[s4 + 3] = v.w;
+                }
+            } else {                                           // pi at the node before this wave's first one
+                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn_l), n0 - 1));
+                const f32x2_t r2 = {r, r}, one2 = {1.0f, 1.0f};
+#pragma unroll
+                for (int s = 0; s < SPL; s += 2) {            // (the very operations of the loop below)
+                    const f32x2_t e2 = {e4[s], e4[s + 1]};
+                    const f32x2_t t = r2 * e2, t1 = t + one2;
+                    const f32x2_t inv = {__builtin_amdgcn_rcpf(t1.x), __builtin_amdgcn_rcpf(t1.y)};
+                    const f32x2_t f = t * inv;
+                    fpv[s] = f.x; fpv[s + 1] = f.y;
+                }
+            }
+#pragma unroll 1
+            for (int c0 = n0; c0 < n1; c0 += TB_CHUNK) {
+                float aI[TB_CHUNK], aP[TB_CHUNK], aQ[TB_CHUNK], aD[TB_CHUNK];
+                float a3[TB_CHUNK], a4[TB_CHUNK];
+#pragma unroll
+                for (int q = 0; q < TB_CHUNK; ++q) {
+                    aI[q] = 0.0f; aP[q] = 0.0f; aQ[q] = 0.0f; aD[q] = 0.0f; a3[q] = 0.0f; a4[q] = 0.0f;
+                    if (c0 + q < n1) {                         // (wave-uniform)
+                        const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn_l), c0 + q));
+                        f32x2_t pS = {0.0f, 0.0f}, pP = {0.0f, 0.0f}, pQ = {0.0f, 0.0f}, pD = {0.0f, 0.0f};
+                        f32x2_t p3 = {0.0f, 0.0f}, p4 = {0.0f, 0.0f};
+                        const f32x2_t r2 = {r, r}, one2 = {1.0f, 1.0f};
+#pragma unroll
+                        for (int s = 0; s < SPL; s += 2) {
+                            const f32x2_t e2 = {e4[s], e4[s + 1]};
+                            const f32x2_t t = r2 * e2, t1 = t + one2;
+                            const f32x2_t inv = {__builtin_amdgcn_rcpf(t1.x), __builtin_amdgcn_rcpf(t1.y)};
+                            const f32x2_t f = t * inv;                                       // pi (:30)
+                            pS += f;
+                            const f32x2_t x = e2 * inv, y = x * inv;
+                            pP += y;                                                         // e/(1+re)^2
+                            const f32x2_t xy = x * y;
+                            pQ += xy;                                                        // e^2/(1+re)^3
+                            if (HI) {
+                                const f32x2_t xyx = xy * x;
+                                p3 += xyx;                                                   // e^3/(1+re)^4
+                                p4 = __builtin_elementwise_fma(xyx, x, p4);                  // e^4/(1+re)^5
+                            }
+                            const f32x2_t d = f - (f32x2_t){fpv[s], fpv[s + 1]};              // pi_k - pi_{k-1}
+                            pD = __builtin_elementwise_fma(d, d, pD);
+                            fpv[s] = f.x; fpv[s + 1] = f.y;
+                        }
+                        aI[q] = pS.x + pS.y; aP[q] = pP.x + pP.y; aQ[q] = pQ.x + pQ.y; aD[q] = pD.x + pD.y;
+                        a3[q] = p3.x + p3.y; a4[q] = p4.x + p4.y;
+                    }
+                }
+                const float tI = wave_reduce8(aI);
+                const float tP = wave_reduce8(aP);
+                const float tQ = wave_reduce8(aQ);
+                const float tD = wave_reduce8(aD);
+                float t3 = 0.0f, t4 = 0.0f;
+                if (HI) { t3 = wave_reduce8(a3); t4 = wave_reduce8(a4); }
+                if ((lane & 7) == 0 && c0 + (lane >> 3) < n1) {
+                    float *dst = sh.wp[0][c0 + (lane >> 3)];
+                    *reinterpret_cast<float4 *>(dst) = make_float4(tI, tP, tQ, tD);
+                    if (HI) *reinterpret_cast<float2 *>(dst + 4) = make_float2(t3, t4);
+                }
+            }
+        };
         constexpr bool HI_OK = TB_BLOCK == 256;
         // (verify -- RLVI_TJ_VERIFY=1 -- forces the verification round: no fourth-order first round, no
         //  acceptance on estimated step errors; the tests hold the two paths against each other)
         const bool hi_round = HI_OK && round == 0 && trace == nullptr && !verify;
         if (active) {     // (threads past TB_BLOCK, if the caller has any, only follow the barriers)
-            if constexpr (HI_OK) {
+            if constexpr (NSPLIT) {
+                if constexpr (HI_OK) {
+                    if (hi_round) sums_split(std::true_type{}); else sums_split(std::false_type{});
+                } else {
+                    sums_split(std::false_type{});
+                }
+            } else if constexpr (HI_OK) {
                 if (hi_round) sums(std::true_type{}); else sums(std::false_type{});
             } else {
                 sums(std::false_type{});
@@ -328,8 +450,12 @@ __device__ __forceinline__ TbSolved trajb_solve(
         //  a lane's write-through stores go out one after the other)
         if (wave < 4 && !dead && lane < Ke) {
             double dq = 0.0;
+            if constexpr (NSPLIT) {
+                dq = (double)sh.wp[0][lane][wave];            // (one wave summed this node over the whole slice)
+            } else {
 #pragma unroll
-            for (int w = 0; w < TB_NW; ++w) dq += (double)sh.wp[w][lane][wave];
+                for (int w = 0; w < TB_NW; ++w) dq += (double)sh.wp[w][lane][wave];
+            }
             gu64 *rec = A + ((size_t)lane * MAX_COOP_WG + b) * XCHG3_GRANULES;
             __hip_atomic_store(rec + wave, ((unsigned long long)tag << 32) | __float_as_uint((float)dq),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -340,12 +466,16 @@ __device__ __forceinline__ TbSolved trajb_solve(
                 for (int w = 1; w < TB_NW; ++w) wmin = fminf(wmin, sh.pmin[w]);
                 __hip_atomic_store(rec + 4, ((unsigned long long)tag << 32) | __float_as_uint(wmin),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dbg != nullptr && b == 0 && round == 0 && lane == 0) dbg[898] = __float_as_uint(wmin);
+                if ((RLVI_STAMPS && dbg != nullptr) && b == 0 && round == 0 && lane == 0) dbg[898] = __float_as_uint(wmin);
             }
             if (wave < 2 && nq > 5) {
                 float hq = 0.0f;
+                if constexpr (NSPLIT) {
+                    hq = sh.wp[0][lane][4 + wave];
+                } else {
 #pragma unroll
-                for (int w = 0; w < TB_NW; ++w) hq += sh.wp[w][lane][4 + wave];
+                    for (int w = 0; w < TB_NW; ++w) hq += sh.wp[w][lane][4 + wave];
+                }
                 __hip_atomic_store(rec + 5 + wave, ((unsigned long long)tag << 32) | __float_as_uint(hq),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -474,7 +604,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
             }
             TB_STAMP();   // totals in
             const float gm = (lane < Ke && nq > 4) ? val[4] : __builtin_inff();
-            if (dbg != nullptr && b == 0 && round == 0) dbg[900 + lane] = ((unsigned long long)nq << 32) | __float_as_uint(val[4]);
+            if ((RLVI_STAMPS && dbg != nullptr) && b == 0 && round == 0) dbg[900 + lane] = ((unsigned long long)nq << 32) | __float_as_uint(val[4]);
             if (HI_OK && hi_round)
                 tj_chain<true, true, HI_OK>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2],
                                             (double)val[3], gm, dead, rn_l, shift, invN, tol, trace, true, xstep,
@@ -496,17 +626,18 @@ __device__ __forceinline__ TbSolved trajb_solve(
         r_fin = sh.out.res_rfin;
         const float delta = sh.out.res_delta;
         const bool found = sh.out.res_found != 0;
-        if (dbg != nullptr && b == 0 && tid == 0 && round < 24)
+        if ((RLVI_STAMPS && dbg != nullptr) && b == 0 && tid == 0 && round < 24)
             dbg[64 + round] = ((unsigned long long)((Ke << 8) | it) << 32) | __float_as_uint(delta);
         rn_l = lane < K ? sh.out.nodes[lane] : 1.0f;
         if (lane == 0) rn_l = (float)(0.95 / (1.0 - 0.95));
-        Ke = found ? round8(it + 2) : K;      // no stop index among the evaluated nodes: all of them
+        Ke = __builtin_amdgcn_readfirstlane(found ? round8(it + 2) : K);      // no stop index among the evaluated nodes: all of them
         if (round == 0) {
             // the true minimum is known now: residuals.sub_(min) (:27, stored by the caller),
             // e = exp(-residuals) (:28)
             gmin = sh.out.res_min;
 #pragma unroll
             for (int j = 0; j < E; ++j) ev[j] = expf(-(l[j] - gmin));      // pads stay 0
+            if (delta > TJ_ACCEPT && !dead) stage_slice(false);             // (another round will read them)
         }
         if (delta <= TJ_ACCEPT) { accepted = true; break; }
         if (dead) break;
@@ -516,7 +647,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
     if (!accepted && !dead && tid == 0) atomicOr(&hdr->status, RLVI_ST_NOCONV);
 
     TB_STAMP();   // solved
-    if (dbg != nullptr && b == 0 && tid == 0) dbg[63] = (unsigned long long)dbgi;
+    if ((RLVI_STAMPS && dbg != nullptr) && b == 0 && tid == 0) dbg[63] = (unsigned long long)dbgi;
     if (b == 0 && tid < WAVE) {
         if (tid == 0) {
             if (out_iters != nullptr) *out_iters = it;

@@ -287,7 +287,7 @@ __device__ __forceinline__ bool thq_load(gu64 *p, uint32_t tag, uint32_t &cnt, u
 // (identical on every workgroup).  All threads call; returns false after a timeout (sh.dead set).
 // Record r = half * 256 + bin lives at slot r of the stage-A row of its workgroup.
 // (stamps go to LDS and are copied out at the end: a global store in front of a barrier would cost its round trip)
-#define THQ_STAMP() do { if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) sh.stamps[dbgi++] = wall_clock64(); } while (0)
+#define THQ_STAMP() do { if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) sh.stamps[dbgi++] = wall_clock64(); } while (0)
 // pt != nullptr (sharded over several GPUs): the bin's publishing wave first pushes this rank's totals
 // into every rank's inbox, adds up what all ranks pushed (integers: exact, order-free) and publishes the
 // global totals; ptag numbers the sharded exchanges of the group (rlvi_trajb.h uses the same counter).
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         state->key = prefix;
         if (pt != nullptr) pt->dtag = ptag - 1u;
         state->valid = (ok && !all_inside) ? 1u : 0u;
-        if (dbg != nullptr) {
+        if ((RLVI_STAMPS && dbg != nullptr)) {
             for (int q = 0; q < dbgi; ++q) dbg[q] = sh.stamps[q];
             dbg[63] = (unsigned long long)dbgi;
         }
