@@ -142,8 +142,22 @@ __device__ __forceinline__ void write_partial(double *part, double ta, double th
                                               double inv_rows100, int accum) {
     double *p = part + (size_t)PART_STRIDE * blockIdx.x;
     const double v0 = ta * (double)inv_scale, v1 = th * inv_rows100;
-    if (accum) { p[0] += v0; p[1] += v1; p[2] += ta; p[3] += th; }
-    else { p[0] = v0; p[1] = v1; p[2] = ta; p[3] = th; }
+#ifndef RLVI_MSTEP_ATOMIC_TAIL
+#define RLVI_MSTEP_ATOMIC_TAIL 1
+#endif
+    if (accum && !RLVI_MSTEP_ATOMIC_TAIL) { p[0] += v0; p[1] += v1; p[2] += ta; p[3] += th; }
+    else if (accum) {
+        // four no-return fp64 adds at the memory side instead of a read-modify-write: the record's old
+        // value never travels, so the last workgroups of a launch end with four posted operations and not
+        // with a load round trip (~1 us) on the launch's critical path.  One adder per record and launch,
+        // launches in stream order: the sums stay order-deterministic.
+        typedef __attribute__((address_space(1))) double gdouble;
+        gdouble *q = (gdouble *)p;
+        __builtin_amdgcn_global_atomic_fadd_f64(q + 0, v0);
+        __builtin_amdgcn_global_atomic_fadd_f64(q + 1, v1);
+        __builtin_amdgcn_global_atomic_fadd_f64(q + 2, ta);
+        __builtin_amdgcn_global_atomic_fadd_f64(q + 3, th);
+    } else { p[0] = v0; p[1] = v1; p[2] = ta; p[3] = th; }
 }
 
 // A row is owned by G consecutive lanes; lane g holds the vectors k*G+g, k < kact <= KMAX, so one
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
     float *__restrict__ residuals, int64_t N, int64_t nfull, int C, float inv_scale,
     T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status, int accum,
-    double inv_rows100) {
+    double inv_rows100, int hold_ticks, int gen_ticks) {
     constexpr int R = WAVE / G;                                   // rows per wave tile
     constexpr int VB = V * (int)sizeof(T);                        // bytes of a lane vector
     constexpr int NI = (KMAX * VB + 15) / 16;                     // 1-KiB pieces per tile (max)
@@ -390,6 +404,15 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
 
     float acc = 0.0f, hits = 0.0f;
     bool bad = false;
+    // Reads first, then writes -- chip-wide, without a word exchanged: when every wave of the launch has ONE
+    // tile (a launch of up to 16 waves x CUs tiles: the bench block), a wave does not issue its gradient
+    // stores before `hold_ticks` x 10 ns after ITS OWN start, the time the launch's reads need at the
+    // read-only rate of the memory system.  Until then the tile waits in the wave's LDS slice, finished.
+    // Stores that start while other waves' tiles are still landing turn the read stream into a mixed
+    // read / write stream (5.4 TB/s instead of 6.5 read-only), and the write burst that follows the read
+    // phase is absorbed by the Infinity Cache and drains while the next launch is being dispatched:
+    // 11.15 -> 10.5 us per launch at 65 536 x 100 (hold 4.0 us; 3.0 and 6.0 us are both slower than none).
+    const unsigned long long t_begin = hold_ticks > 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     for (int64_t t = (int64_t)blockIdx.x * WPB + wave; t < nfull; t += tstride) {
         const int64_t row_base = t * R;
@@ -543,6 +566,11 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
 #else
 #define RLVI_TILE_STORE(val, ptr) (*(ptr) = (val))
 #endif
+        if (hold_ticks > 0) {
+            while (__builtin_amdgcn_s_memrealtime() - t_begin < (unsigned long long)hold_ticks)
+                __builtin_amdgcn_s_sleep(4);
+            hold_ticks = gen_ticks > 0 ? hold_ticks + gen_ticks : 0;      // (lab: one hold per generation of tiles)
+        }
         if (grad != nullptr) {
             char *gdst = reinterpret_cast<char *>(grad + row_base * C);
             vu4 st[NI];
@@ -581,6 +609,16 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
         for (int w = 0; w < WPB; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
         write_partial(part, ta, th, inv_scale, inv_rows100, accum);
     }
+}
+
+// Hold of the reads-then-writes form for a launch that reads `bytes` of logits, in ticks of 10 ns: the time
+// its reads need at the read-only rate.  Fitted to the best hold of a sweep per shape (tools/sweep_hold.sh:
+// 13.6 MB bf16 -> 2.4 us, 16.8 MB -> 2.9, 19.7 MB -> 3.4, 26.2 MB -> 4.3, 33.5 MB -> 5.2): 0.68 us of ramp-up
+// + bytes / 7.25 TB/s; within +-0.3 us of the best hold most of the gain stays, 1 us off is worse than
+// none.  Below 12 MB no hold was found to help (the launch is over before the phases could separate).
+static inline int mstep_hold_ticks(double bytes) {
+    if (bytes < 12.0e6) return 0;
+    return (int)((0.68 + bytes / 7.25e6) * 100.0);
 }
 
 __global__ __launch_bounds__(256) void mstep_finalize_kernel(double *__restrict__ part, int nblocks,
@@ -622,14 +660,21 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         // (RLVI_MSTEP_LDS_PAD: extra LDS per workgroup = fewer resident workgroups per CU; with the grid
         //  uncapped the dispatcher then hands the remaining tiles to whichever CU frees up first)
         const size_t lds = (size_t)WPB * SKB * 1024 + (size_t)tune_get("RLVI_MSTEP_LDS_PAD", 0);
+        // reads-then-writes hold (see the kernel): only when no wave has a second tile and a gradient is
+        // written; RLVI_MSTEP_HOLD = ticks of 10 ns (0: off, -1: from the bytes the launch reads)
+        int hold_ticks = tune_get("RLVI_MSTEP_HOLD", -1);
+        const int gen_ticks = tune_get("RLVI_MSTEP_GEN", 0);
+        if (grad == nullptr || (nfull > nb * WPB && gen_ticks <= 0 && hold_ticks < 0)) hold_ticks = 0;
+        if (hold_ticks < 0)
+            hold_ticks = mstep_hold_ticks((double)(nfull < nb * WPB ? nfull : nb * WPB) * (double)wtile_bytes);
         if (kact == KMAX)
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, true>, dim3((unsigned)nb), dim3(WPB * WAVE),
                         lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
-                        part, status, accum, inv_rows100);
+                        part, status, accum, inv_rows100, hold_ticks, gen_ticks);
         else
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, false>, dim3((unsigned)nb), dim3(WPB * WAVE),
                         lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
-                        part, status, accum, inv_rows100);
+                        part, status, accum, inv_rows100, hold_ticks, gen_ticks);
         const int64_t done = nfull * R;
         if (rc == 0 && done < B) {
             // the B mod R trailing rows: one workgroup of the register-row kernel, adding to record 0
