@@ -237,6 +237,13 @@ __device__ __forceinline__ TbSolved trajb_solve(
         }
     };
     stage_slice(true);
+    // (node-split: the workgroup's minimum is known to every wave from here on -- each wave publishes the
+    //  records of its own nodes itself, the minimum included)
+    float wmin_all = __builtin_inff();
+    if constexpr (NSPLIT) {
+#pragma unroll
+        for (int w = 0; w < TB_NW; ++w) wmin_all = fminf(wmin_all, sh.pmin[w]);
+    }
     TB_STAMP();   // slice loaded
 
     const float invN = 1.0f / (float)N;
@@ -254,6 +261,15 @@ __device__ __forceinline__ TbSolved trajb_solve(
         // HI: the first round also takes R3 = sum e^3/(1+re)^4 and R4 = sum e^4/(1+re)^5, the third- and
         // fourth-order terms of S around the node: with them the corrected nodes are good enough (and
         // provably so) for tj_chain to accept without a verification round
+        constexpr bool HI_OK = TB_BLOCK == 256;
+        // (verify -- RLVI_TJ_VERIFY=1 -- forces the verification round: no fourth-order first round, no
+        //  acceptance on estimated step errors; the tests hold the two paths against each other)
+        const bool hi_round = HI_OK && round == 0 && trace == nullptr && !verify;
+        gu64 *A = bufA + (size_t)(xstep & 1) * TJ_MAXK * MAX_COOP_WG * XCHG3_GRANULES;
+        // (every replica on its own 3-KiB stretch: 256 pollers on one 768-byte stretch serialise at the
+        //  memory side)
+        gu64 *B = bufB + (size_t)(xstep & 1) * XCHG3B_REPLICAS * TJ_MAXK * XCHG3_GRANULES;
+        const int nq = hi_round ? 7 : (round == 0 ? 5 : 4);      // granules of a record that carry this step's tag
         auto sums = [&](auto hi_tag) {
             constexpr bool HI = decltype(hi_tag)::value;
 #pragma unroll 1
@@ -414,17 +430,23 @@ __device__ __forceinline__ TbSolved trajb_solve(
                 const float tD = wave_reduce8(aD);
                 float t3 = 0.0f, t4 = 0.0f;
                 if (HI) { t3 = wave_reduce8(a3); t4 = wave_reduce8(a4); }
-                if ((lane & 7) == 0 && c0 + (lane >> 3) < n1) {
-                    float *dst = sh.wp[0][c0 + (lane >> 3)];
-                    *reinterpret_cast<float4 *>(dst) = make_float4(tI, tP, tQ, tD);
-                    if (HI) *reinterpret_cast<float2 *>(dst + 4) = make_float2(t3, t4);
+                // stage A straight from the registers: after the butterflies all eight lanes of a group hold
+                // their node's totals, so lane 8 s + j stores granule j of node c0 + s -- one write-through
+                // store per lane, no LDS, no workgroup barrier, and a wave's records leave as soon as THAT
+                // wave is through with its nodes
+                {
+                    const int sl = lane >> 3, j = lane & 7;
+                    const int node = c0 + sl;
+                    if (node < n1 && j < nq && !dead) {
+                        const float v = j == 0 ? tI : j == 1 ? tP : j == 2 ? tQ : j == 3 ? tD : j == 4 ? wmin_all
+                                        : j == 5 ? t3 : t4;
+                        __hip_atomic_store(A + ((size_t)node * MAX_COOP_WG + b) * XCHG3_GRANULES + j,
+                                           ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         };
-        constexpr bool HI_OK = TB_BLOCK == 256;
-        // (verify -- RLVI_TJ_VERIFY=1 -- forces the verification round: no fourth-order first round, no
-        //  acceptance on estimated step errors; the tests hold the two paths against each other)
-        const bool hi_round = HI_OK && round == 0 && trace == nullptr && !verify;
         if (active) {     // (threads past TB_BLOCK, if the caller has any, only follow the barriers)
             if constexpr (NSPLIT) {
                 if constexpr (HI_OK) {
@@ -439,23 +461,14 @@ __device__ __forceinline__ TbSolved trajb_solve(
             }
         }
         TB_STAMP();   // sums done
-        __syncthreads();
-        gu64 *A = bufA + (size_t)(xstep & 1) * TJ_MAXK * MAX_COOP_WG * XCHG3_GRANULES;
-        // (every replica on its own 3-KiB stretch: 256 pollers on one 768-byte stretch serialise at the
-        //  memory side)
-        gu64 *B = bufB + (size_t)(xstep & 1) * XCHG3B_REPLICAS * TJ_MAXK * XCHG3_GRANULES;
-        const int nq = hi_round ? 7 : (round == 0 ? 5 : 4);      // granules of a record that carry this step's tag
+        if constexpr (!NSPLIT) __syncthreads();
         // ---- stage A: this workgroup's record of every evaluated node
         // (waves 0..3 each combine the wave partials and store ONE granule per lane -- S, S', Q, D;
         //  a lane's write-through stores go out one after the other)
-        if (wave < 4 && !dead && lane < Ke) {
+        if (!NSPLIT && wave < 4 && !dead && lane < Ke) {
             double dq = 0.0;
-            if constexpr (NSPLIT) {
-                dq = (double)sh.wp[0][lane][wave];            // (one wave summed this node over the whole slice)
-            } else {
 #pragma unroll
-                for (int w = 0; w < TB_NW; ++w) dq += (double)sh.wp[w][lane][wave];
-            }
+            for (int w = 0; w < TB_NW; ++w) dq += (double)sh.wp[w][lane][wave];
             gu64 *rec = A + ((size_t)lane * MAX_COOP_WG + b) * XCHG3_GRANULES;
             __hip_atomic_store(rec + wave, ((unsigned long long)tag << 32) | __float_as_uint((float)dq),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -470,12 +483,8 @@ __device__ __forceinline__ TbSolved trajb_solve(
             }
             if (wave < 2 && nq > 5) {
                 float hq = 0.0f;
-                if constexpr (NSPLIT) {
-                    hq = sh.wp[0][lane][4 + wave];
-                } else {
 #pragma unroll
-                    for (int w = 0; w < TB_NW; ++w) hq += sh.wp[w][lane][4 + wave];
-                }
+                for (int w = 0; w < TB_NW; ++w) hq += sh.wp[w][lane][4 + wave];
                 __hip_atomic_store(rec + 5 + wave, ((unsigned long long)tag << 32) | __float_as_uint(hq),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
