@@ -379,6 +379,10 @@ def main():
         else:
             ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
 
+    # every block of the rotation streams from HBM (12 x 52 MB between two uses of a line): tell the M-step
+    # launcher so -- reads first, then writes (ops.hint_logits_from_hbm, mstep.hip); the single-buffer leg
+    # below (mstep_warm_us: the block stays in the Infinity Cache) runs without the hint
+    ops.hint_logits_from_hbm(True)
     estep_mode = ["replicated" if use_dist else "single"]
     estep_note = ""
     status_log = []        # every non-zero device status seen after a leg: it stays in the JSON line
@@ -584,6 +588,7 @@ def main():
                                 "; residuals all-gathered, E-step replicated on every rank"),
                    "rows_per_gpu": B, "classes": C, "n_samples": N,
                    "launch": launch_mode.get("step", "eager"), "estep_dist": estep_mode[0],
+                   "mstep_logits": "hinted as streaming from HBM (ops.hint_logits_from_hbm: reads first, then writes)",
                    **({"estep_dist_note": estep_note} if estep_note else {}),
                    **({"estep_dist_setup_s": round(setup_s, 3)} if setup_s is not None else {})},
     }
@@ -604,7 +609,9 @@ def main():
         def mstep_warm(i, ws):
             ops.mstep_fwd_bwd(logits[0], labels, idx_local, weights, residuals, inv_scale=inv_scale,
                               grad=grads[0], ws=ws, accumulate=True)
+        ops.hint_logits_from_hbm(False)
         extra["mstep_warm_us"] = timed(mstep_warm, K, W, use_graph) / K * 1e3
+        ops.hint_logits_from_hbm(True)
         # threshold + truncation over N samples (the epoch end once `overfit` is set; V4)
         thr_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         w_thr = weights.clone()

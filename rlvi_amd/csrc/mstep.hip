@@ -661,8 +661,14 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         //  uncapped the dispatcher then hands the remaining tiles to whichever CU frees up first)
         const size_t lds = (size_t)WPB * SKB * 1024 + (size_t)tune_get("RLVI_MSTEP_LDS_PAD", 0);
         // reads-then-writes hold (see the kernel): only when no wave has a second tile and a gradient is
-        // written; RLVI_MSTEP_HOLD = ticks of 10 ns (0: off, -1: from the bytes the launch reads)
-        int hold_ticks = tune_get("RLVI_MSTEP_HOLD", -1);
+        // written.  RLVI_MSTEP_HOLD = ticks of 10 ns; 0 (the default): off; -1: from the bytes the launch
+        // reads AT THE HBM READ RATE -- for logits that stream from HBM (a block that is not resident in the
+        // Infinity Cache: bench.py's rotation of twelve blocks, a block larger than the cache).  Logits that
+        // the model's last layer has just written are served by the cache, their read phase is over sooner
+        // than the hold assumes, and the hold then COSTS time (single buffer pair: 9.4 -> 10.3 us): the
+        // caller knows which case it is in, the kernel does not (a per-CU barrier between reads and writes
+        // -- 16-wave workgroups -- was built to let the data decide: no gain cold, 9.4 -> 10.1 us warm).
+        int hold_ticks = tune_get("RLVI_MSTEP_HOLD", 0);
         const int gen_ticks = tune_get("RLVI_MSTEP_GEN", 0);
         if (grad == nullptr || (nfull > nb * WPB && gen_ticks <= 0 && hold_ticks < 0)) hold_ticks = 0;
         if (hold_ticks < 0)

@@ -135,6 +135,18 @@ def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_
     return out, grad
 
 
+def hint_logits_from_hbm(flag=True):
+    """Tell the M-step launcher where its logits come from (process-wide, from the next launch on).
+
+    True: the [B, C] block streams from HBM -- it is larger than the Infinity Cache, or (bench.py) one of
+    many blocks touched in rotation.  A one-tile-per-wave launch of 12 MB and more then holds its gradient
+    stores until its reads have had their time at the HBM read rate (reads first, then writes, chip-wide:
+    mstep.hip), 11.8 -> 10.7 us at 65 536 x 100.  False (the default): the block was just written by the
+    model's last layer and is served by the cache -- what train_rlvi sees -- where the same hold would cost
+    time (9.4 -> 10.3 us)."""
+    _lib.check(_lib.load().rlvi_tune_set(b"RLVI_MSTEP_HOLD", -1 if flag else 0), "rlvi_tune_set")
+
+
 class MStepLoop:
     """mstep_fwd_bwd(..., accumulate=True) for a training loop, validated ONCE: the per-epoch vectors
     (weights, residuals), the workspace, the stream and the ctypes entry are fixed when the object is made

@@ -196,6 +196,33 @@ def test_mstep_bench_size_properties_and_oracle(gpu, oracle):
     assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
 
 
+def test_mstep_reads_then_writes_hold_changes_no_bit(gpu):
+    """ops.hint_logits_from_hbm(True): a one-tile-per-wave launch holds its gradient stores until its reads
+    have had their time (mstep.hip).  It is a matter of WHEN the stores leave, never of what they carry:
+    gradient, residuals and the batch scalars are bit-identical with and without the hint, also for an
+    explicit, absurdly long hold."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    B, C = 65536, 100
+    d = synth.mstep_inputs(B, C, seed=21)
+    z = torch.from_numpy(d["logits"]).to(dev)
+    lab, idx = torch.from_numpy(d["labels"]).to(dev), torch.from_numpy(d["idx"]).to(dev)
+    w = torch.from_numpy(d["weights"]).to(dev)
+    got = []
+    try:
+        for knob in (0, -1, 1500):
+            _lib.check(_lib.load().rlvi_tune_set(b"RLVI_MSTEP_HOLD", knob), "tune")
+            res = torch.zeros(B, device=dev)
+            out, grad = ops.mstep_fwd_bwd(z, lab, idx, w, res)
+            torch.cuda.synchronize()
+            got.append((out.cpu().numpy(), grad.cpu().numpy(), res.cpu().numpy()))
+    finally:
+        ops.hint_logits_from_hbm(False)
+    for o, g, r in got[1:]:
+        assert np.array_equal(o, got[0][0]) and np.array_equal(g, got[0][1]) and np.array_equal(r, got[0][2])
+    assert dev_status(ops, dev) == 0
+
+
 def test_mstep_accumulate_and_epoch_end(gpu, oracle):
     """Accumulate mode: three ragged mini-batches, one launch each, then rlvi_epoch_end_f32
     (E-step + truncation + scalar reduction) == the reference's epoch tail (:99-105)."""

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 from rlvi_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="mstep", choices=["mstep", "mstep_out", "estep", "thr", "fused", "mstep_fwd", "step"])
+ap.add_argument("--what", default="mstep", choices=["mstep", "mstep_warm", "mstep_out", "estep", "thr", "fused", "mstep_fwd", "step"])
 ap.add_argument("--rows", type=int, default=65536)
 ap.add_argument("--classes", type=int, default=100)
 ap.add_argument("--n", type=int, default=0, help="E-step / threshold vector length (default rows)")
@@ -52,6 +52,8 @@ with torch.cuda.stream(side):
         r = i % bench.ROTATE
         if a.what == "mstep":
             ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, grad=grads[r], ws=ws, accumulate=True)
+        elif a.what == "mstep_warm":       # one buffer pair: the block stays in the Infinity Cache
+            ops.mstep_fwd_bwd(logits[0], labels, idx, weights, residuals, grad=grads[0], ws=ws, accumulate=True)
         elif a.what == "mstep_out":
             ops.mstep_fwd_bwd(logits[r], labels, idx, weights, residuals, out=out, grad=grads[r], ws=ws)
         elif a.what == "step":
@@ -98,7 +100,7 @@ with torch.cuda.stream(side):
 
     def describe(best):
         extra = ""
-        if a.what in ("mstep", "mstep_fwd", "mstep_out"):
+        if a.what in ("mstep", "mstep_warm", "mstep_fwd", "mstep_out"):
             s = 2 if a.dtype == "bf16" else 4
             byt = B * ((1 if a.what == "mstep_fwd" else 2) * C * s + 24)
             extra = f" {byt / best / 1e3:8.1f} GB/s  frac {byt / best / 1e3 / 8000:.3f}"
