@@ -46,6 +46,10 @@ __global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMP
     }
     __shared__ TbShared<TB_BLOCK / WAVE, tb_stage(E, TB_BLOCK)> sh;
     const int tid = threadIdx.x;
+#if RLVI_STAMPS
+    // (lab build: shader clock of this launch = delta s_memtime / delta s_memrealtime x 100 MHz)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int b = (int)blockIdx.x;
     const int64_t L = (N + G - 1) / G;
     const int64_t lo = (int64_t)b * L < N ? (int64_t)b * L : N;
@@ -67,6 +71,12 @@ __global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMP
                                                 ws, dbg, pt, verify != 0);
     // a wait that timed out (RLVI_ST_TIMEOUT: the workgroups were not all resident) leaves the
     // caller's residuals and pi as they were -- the host raises on the status; it never hands out garbage
+#if RLVI_STAMPS
+    if (dbg != nullptr && blockIdx.x == 0 && tid == 0) {
+        dbg[960] = __builtin_amdgcn_s_memtime() - clk0;
+        dbg[961] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
     if (s.dead) return;
     const float pmax = tb_pmax(s);
 #pragma unroll

@@ -31,7 +31,7 @@ struct TjOut {
     // node at a time (an LDS broadcast read: two 16-byte reads per step, asked for one step ahead, instead
     // of six v_readlane whose SGPR results each cost the wave wait states before a vector instruction may
     // use them): {r', a0, b, c, R3, R4, -, -}
-    alignas(16) float coef[TJ_MAXK + 1][8];
+    alignas(16) float coef[TJ_MAXK + 2][8];
 };
 
 // Neighbour lanes and an affine scan over the 64 lanes without the LDS crossbar (a __shfl is a
@@ -101,11 +101,11 @@ __device__ __forceinline__ void wave_sort_keys(float &key, int &src) {
 // fourth-order terms of S around the node) are given too; the chain then runs on the fourth-order
 // model and may ACCEPT THE ROUND WITHOUT A VERIFICATION ROUND (see below).
 template <bool FIRST, bool HASQ = true, bool HI = false>
-__device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, double tP, double tQ,
-                                         double tD,
+__device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, float tP, float tQ,
+                                         float tD,
                                          float gmin, bool dead, float rn_l, float shift, float invN,
                                          float tol, float *trace, bool want_nodes, int xstep,
-                                         unsigned long long *dbg, double tR3 = 0.0, double tR4 = 0.0) {
+                                         unsigned long long *dbg, float tR3 = 0.0f, float tR4 = 0.0f) {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool has = lane < Ke;
     // RLVI_TJ_DEBUG: where the recurrence wave's time goes (first round of workgroup 0)
@@ -121,27 +121,26 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     }
     const float rn = rn_l * scale;
     // (a node far below the trajectory may legitimately have S = 0 after fp32 underflow)
-    bool finite = has ? (tS == tS && tP == tP && tD == tD && tQ == tQ && tS < 1e300 && tP < 1e300 &&
-                             tD < 1e300 && tQ < 1e300)
-                      : true;
-    if (HI && has) finite = finite && tR3 == tR3 && tR4 == tR4 && tR3 < 1e300 && tR4 < 1e300;
+    const float finf = __builtin_inff();          // (x < inf is false for +inf and for NaN)
+    bool finite = has ? (tS < finf && tP < finf && tD < finf && tQ < finf) : true;
+    if (HI && has) finite = finite && tR3 < finf && tR4 < finf;
     const bool round_ok = __all(finite) && scale > 1e-6f && scale < 1e6f && !dead;
     if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && xstep == 0) {
-        if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong(tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong(tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong(tQ); }
+        if (lane < 8) { dbg[104 + 3 * lane] = (unsigned long long)__double_as_longlong((double)tS); dbg[105 + 3 * lane] = (unsigned long long)__double_as_longlong((double)tP); dbg[106 + 3 * lane] = (unsigned long long)__double_as_longlong((double)tQ); }
         if (lane == 0) { dbg[102] = __ballot(finite); dbg[103] = __float_as_uint(scale); }
     }
 
     // lane-parallel: a0 = mean(pi) at the node, b = d mean / dr, err = ||new - old||_2
-    const float a0_l = has ? (float)tS * invN : 0.0f;                                // (:35)
+    const float a0_l = has ? tS * invN : 0.0f;                                // (:35)
     // (FIRST: tP, tQ are derivatives with respect to r' = r / scale; b and c only steer the
     //  correction, fp32 is plenty)
     const float iscale = FIRST ? __builtin_amdgcn_rcpf(scale) : 1.0f;
-    const float b_l = has ? (float)tP * invN * iscale : 0.0f;
-    const float c_l = has ? (float)tQ * invN * iscale * iscale : 0.0f;
+    const float b_l = has ? tP * invN * iscale : 0.0f;
+    const float c_l = has ? tQ * invN * iscale * iscale : 0.0f;
     // (mean-pi units, like b and c; P2 stays a plain sum: D = h^2 * P2)
-    const float r3_l = (HI && has) ? (float)tR3 * invN * iscale * iscale * iscale : 0.0f;
-    const float r4_l = (HI && has) ? (float)tR4 * invN * iscale * iscale * iscale * iscale : 0.0f;
-    const float err_l = has ? sqrtf((float)tD) : __builtin_inff();                   // (:33)
+    const float r3_l = (HI && has) ? tR3 * invN * iscale * iscale * iscale : 0.0f;
+    const float r4_l = (HI && has) ? tR4 * invN * iscale * iscale * iscale * iscale : 0.0f;
+    const float err_l = has ? sqrtf(tD) : __builtin_inff();                   // (:33)
     const unsigned long long stopmask = __ballot(has && err_l < tol);                // (:36)
     const int it_now = stopmask ? (int)__builtin_ctzll(stopmask) + 1 : Ke;
     const bool found = stopmask != 0ull || Ke >= Ka;
@@ -200,20 +199,40 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
                 if (lane == 0) *reinterpret_cast<float4 *>(out.coef[TJ_MAXK]) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
             }
             __builtin_amdgcn_wave_barrier();
-            float4 ca = *reinterpret_cast<const float4 *>(out.coef[0]);
-            float2 cb = *reinterpret_cast<const float2 *>(out.coef[0] + 4);
-#pragma unroll 1
-            for (int step = 0; step < steps; ++step) {
-                const float4 na = *reinterpret_cast<const float4 *>(out.coef[step + 1]);     // (one step ahead)
-                const float2 nb = *reinterpret_cast<const float2 *>(out.coef[step + 1] + 4);
-                if (lane == step) rnew_l = r;
+            // two register sets, two steps per trip: the operands of step k + 1 are asked for BEFORE the
+            // arithmetic of step k, so the LDS latency (~100 clocks) runs beside a step instead of in front of
+            // every one (written out by hand: with one set and a copy the compiler rotates the loop and the
+            // read lands at the top of the step that needs it)
+            // (a step leaves {r_k, avg_k} in the node's slot of the operand table -- one LDS store -- and the
+            //  lanes fetch their own node's pair after the loop: a compare and two selects less per step)
+            auto chain_step = [&](int step, const float4 &ca, const float2 &cb) {
                 const float dr = r - ca.x;
                 const float dr2 = dr * dr;
                 const float lo2 = fmaf(dr, ca.z, ca.y), hi2 = fmaf(dr, cb.x, -ca.w);
                 const float avg = fmaf(dr2 * dr2, -cb.y, fmaf(dr2, hi2, lo2));
-                if (lane == step) avg_l = avg;
+                *reinterpret_cast<float2 *>(out.coef[step] + 6) = make_float2(r, avg);
                 r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
-                ca = na; cb = nb;
+            };
+            float4 a0v = *reinterpret_cast<const float4 *>(out.coef[0]);
+            float2 b0v = *reinterpret_cast<const float2 *>(out.coef[0] + 4);
+            int step = 0;
+#pragma unroll 1
+            for (; step + 1 < steps; step += 2) {
+                const float4 a1v = *reinterpret_cast<const float4 *>(out.coef[step + 1]);
+                const float2 b1v = *reinterpret_cast<const float2 *>(out.coef[step + 1] + 4);
+                __builtin_amdgcn_sched_barrier(0);             // (the reads are issued HERE, ahead of the step)
+                chain_step(step, a0v, b0v);
+                a0v = *reinterpret_cast<const float4 *>(out.coef[step + 2]);
+                b0v = *reinterpret_cast<const float2 *>(out.coef[step + 2] + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                chain_step(step + 1, a1v, b1v);
+            }
+            if (step < steps) chain_step(step, a0v, b0v);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < steps) {
+                const float2 ra = *reinterpret_cast<const float2 *>(out.coef[lane] + 6);
+                rnew_l = ra.x;
+                avg_l = ra.y;
             }
         } else {
 #pragma unroll 1
@@ -399,7 +418,7 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, double tS, 
     // If every stop test up to `it` clears tol by 8x that margin, the stop index cannot change
     // any more, and neither can pi: no verification round needed.  (Not when the caller asked
     // for the error trace: that wants the errors themselves.)
-    const float rp_l = __shfl_up(rn, 1, WAVE);
+    const float rp_l = lane_up1(rn);
     if (delta_w > TJ_ACCEPT && delta_w <= 1e-3f && trace == nullptr) {
         float u = 0.0f;
         if (has && lane < it_now && lane > 0) {

@@ -615,15 +615,14 @@ __device__ __forceinline__ TbSolved trajb_solve(
             const float gm = (lane < Ke && nq > 4) ? val[4] : __builtin_inff();
             if ((RLVI_STAMPS && dbg != nullptr) && b == 0 && round == 0) dbg[900 + lane] = ((unsigned long long)nq << 32) | __float_as_uint(val[4]);
             if (HI_OK && hi_round)
-                tj_chain<true, true, HI_OK>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2],
-                                            (double)val[3], gm, dead, rn_l, shift, invN, tol, trace, true, xstep,
-                                            dbg, (double)val[5], (double)val[6]);
+                tj_chain<true, true, HI_OK>(sh.out, Ke, K, val[0], val[1], val[2], val[3], gm, dead, rn_l, shift,
+                                            invN, tol, trace, true, xstep, dbg, val[5], val[6]);
             else if (round == 0)
-                tj_chain<true>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2], (double)val[3],
+                tj_chain<true>(sh.out, Ke, K, val[0], val[1], val[2], val[3],
                                gm, dead,
                                rn_l, shift, invN, tol, trace, true, xstep, dbg);
             else
-                tj_chain<false>(sh.out, Ke, K, (double)val[0], (double)val[1], (double)val[2], (double)val[3],
+                tj_chain<false>(sh.out, Ke, K, val[0], val[1], val[2], val[3],
                                gm, dead,
                                 rn_l, shift, invN, tol, trace, true, xstep, dbg);
         }

@@ -162,5 +162,8 @@ with torch.cuda.stream(side):
         print("  slope  :", np.array(ee & 0xFFFFFFFF, np.uint32).view(np.float32)[:24])
         cs = full[990:996].astype(np.int64)
         print("recurrence wave [entry, prepared, chain, trust/tail, acceptance, out] us:", [round(float(v - cs[0]) / 100.0, 2) for v in cs])
+        if int(full[961]) > 0:
+            print(f"shader clock in the E-step kernel: {int(full[960]) / int(full[961]) * 0.1:.2f} GHz "
+                  f"({int(full[960])} cycles in {int(full[961]) / 100.0:.2f} us)")
         print("rounds (it, delta):", [(int(x >> 32), float(np.array([x & 0xFFFFFFFF], np.uint32).view(np.float32)[0])) for x in rd if x][:12])
     print(f"{a.tag or a.what:28s} B={B} C={C} N={N} {a.dtype}: {best:8.2f} us/launch{extra}  status={ws.status()}")
