@@ -31,19 +31,18 @@ namespace rlvi {
 
 // (one-sample slices at 256 threads: three waves per SIMD -- at most 168 registers -- so that the occupancy
 //  query proves 512 workgroups co-resident and the full 256 + 1 grid keeps its one-sample slices)
+// (measured and not kept, round 3: 512-thread workgroups whose second four waves hold no samples and only take
+//  their share of the nodes in the sums, as the in-batch kernel's spare waves do -- 22.1 against 21.9 us per step)
 template <int E, int TB_BLOCK>
 __global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMPS) ? 3 : 1) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
     float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G,
     int64_t Nall, PeerTable *__restrict__ pt, int verify) {
-    // G <= TB_G exchanging workgroups (what is provably co-resident on this device), block G = the
-    // epoch-end reduction
-    if ((int)blockIdx.x == G) {   // epoch end: reduce + clear the M-step records (own CU)
-        double *part = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF);
-        reduce_partials(part, MSTEP_MAX_BLOCKS, mstep_scale, mstep_out, true, TB_BLOCK);
-        return;
-    }
+    // G <= TB_G exchanging workgroups (what is provably co-resident on this device).  The epoch end's
+    // reduction of the M-step records (mstep_out != nullptr) is done by workgroup G - 1 inside the solve, in
+    // the time it would otherwise wait for the first round's totals -- no extra workgroup (round 2 had one:
+    // 257 workgroups on 256 CUs, which is what forced this kernel under 168 registers)
     __shared__ TbShared<TB_BLOCK / WAVE, tb_stage(E, TB_BLOCK)> sh;
     const int tid = threadIdx.x;
 #if RLVI_STAMPS
@@ -68,11 +67,11 @@ __global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMP
         q0[j] = ok ? wts[i] : 0.0f;
     }
     const TbSolved s = trajb_solve<E, TB_BLOCK>(sh, wm, l, q0, ev, true, b, G, Nall, tol, K, out_iters, trace,
-                                                ws, dbg, pt, verify != 0);
+                                                ws, dbg, pt, verify != 0, mstep_out, mstep_scale);
     // a wait that timed out (RLVI_ST_TIMEOUT: the workgroups were not all resident) leaves the
     // caller's residuals and pi as they were -- the host raises on the status; it never hands out garbage
 #if RLVI_STAMPS
-    if (dbg != nullptr && blockIdx.x == 0 && tid == 0) {
+    if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         dbg[960] = __builtin_amdgcn_s_memtime() - clk0;
         dbg[961] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
@@ -106,7 +105,7 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     // from 1e6 on (whole step / eager call, hipGraph): 512 threads only for slices beyond 4096
     const int blk = tune_get("RLVI_TB_BLOCK", 0);
     unsigned long long *dbg = (debug && !dry_run) ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
-    const int extra = mstep_out != nullptr ? 1 : 0;
+    const int extra = 0;      // (the epoch-end reduction rides on workgroup G - 1)
     const int64_t Nall = sharded ? n_all : N;
     PeerTable *pt = (sharded && !dry_run) ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
     const int verify = tune_get("RLVI_TJ_VERIFY", 0);      // 1: always run the verification round

@@ -169,7 +169,8 @@ __device__ __forceinline__ TbSolved trajb_solve(
     TbShared<TB_BLOCK / WAVE, tb_stage(E, TB_BLOCK)> &sh, const TbWarm &wm, const float (&l)[E], const float (&q0)[E],
     float (&ev)[E], const bool active, const int b, const int G, const int64_t N, const float tol,
     const int K, int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
-    unsigned long long *__restrict__ dbg, PeerTable *__restrict__ pt = nullptr, const bool verify = false) {
+    unsigned long long *__restrict__ dbg, PeerTable *__restrict__ pt = nullptr, const bool verify = false,
+    float *__restrict__ red_out = nullptr, const double red_scale = 1.0) {
     int dbgi = 0;
 #define TB_STAMP() do { if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = wall_clock64(); } while (0)
     TB_STAMP();
@@ -461,6 +462,12 @@ __device__ __forceinline__ TbSolved trajb_solve(
             }
         }
         TB_STAMP();   // sums done
+        // the epoch end's reduction of the M-step records (train_rlvi.py:86-87,:105), by the last workgroup,
+        // whose records are out and which has nothing to do until the totals arrive (it reduces no node
+        // unless G == Ke == 64): reads, sums and clears the 1024 x 4 doubles, writes the four scalars
+        if (red_out != nullptr && round == 0 && b == G - 1)
+            reduce_partials(reinterpret_cast<double *>(wsb + WS_PART_OFF), MSTEP_MAX_BLOCKS, red_scale, red_out, true,
+                            NGRP * TB_BLOCK);
         if constexpr (!NSPLIT) __syncthreads();
         // ---- stage A: this workgroup's record of every evaluated node
         // (waves 0..3 each combine the wave partials and store ONE granule per lane -- S, S', Q, D;
