@@ -33,8 +33,11 @@ namespace rlvi {
 //  query proves 512 workgroups co-resident and the full 256 + 1 grid keeps its one-sample slices)
 // (measured and not kept, round 3: 512-thread workgroups whose second four waves hold no samples and only take
 //  their share of the nodes in the sums, as the in-batch kernel's spare waves do -- 22.1 against 21.9 us per step)
+#ifndef RLVI_TB_MINW
+#define RLVI_TB_MINW 3
+#endif
 template <int E, int TB_BLOCK>
-__global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMPS) ? 3 : 1) void estep_trajb_kernel(
+__global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMPS) ? RLVI_TB_MINW : 1) void estep_trajb_kernel(
     float *__restrict__ res, float *__restrict__ wts, int64_t N, float tol, int K,
     int32_t *__restrict__ out_iters, float *__restrict__ trace, void *ws,
     float *__restrict__ mstep_out, double mstep_scale, unsigned long long *__restrict__ dbg, int G,

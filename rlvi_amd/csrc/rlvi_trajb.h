@@ -20,23 +20,24 @@ typedef unsigned int tb_vu4 __attribute__((ext_vector_type(4)));
 #ifndef RLVI_TB_G
 #define RLVI_TB_G 256
 #endif
-// 256 exchanging workgroups (+1 for the epoch-end reduction, which then shares a CU): at the bench
-// size a slice is exactly one sample per thread (32.6 us per step against 33.9 with 240).
+// 256 exchanging workgroups (the epoch-end reduction rides on the last one): at the bench size a slice is
+// exactly one sample per thread (32.6 us per step against 33.9 with 240).
 constexpr int TB_G = RLVI_TB_G;      // exchanging workgroups at most (= exchange slots per node)
 constexpr int TB_CHUNK = 8;
 constexpr int TB_NV = 8;             // values of a record: {S, P, Q, D, min, R3, R4, -}
 constexpr int TB_PER = (TB_G + WAVE - 1) / WAVE;   // polling waves of a stage-A gather
 
-// Node-split sums (slices up to TB_NSPLIT_MAXE samples per thread): the slice's e = exp(-(l - min)) and
+// Node-split sums (slices up to TB_NSPLIT_MAXS samples per workgroup): the slice's e = exp(-(l - min)) and
 // the caller's pi are staged through LDS so that EVERY wave sees all samples and the waves share out the
 // NODES instead of the samples (see `sums_split` below).
 constexpr int TB_NSPLIT_MAXS = 1024;     // node-split up to this many samples per workgroup (16 per lane)
 constexpr bool tb_nsplit(int E, int block) { return E * block <= TB_NSPLIT_MAXS; }
 constexpr int tb_stage(int E, int block) { return tb_nsplit(E, block) ? E * block : 4; }
 
+// STAGE > 4 <=> node-split: then no wave partials go through LDS at all (records leave from the registers)
 template <int TB_NW, int STAGE = 4>
 struct TbShared {
-    float wp[TB_NW][TJ_MAXK][8];     // wave partials {S, P, Q, D, R3, R4, P2, -} per node ([0] alone: node-split)
+    float wp[STAGE > 4 ? 1 : TB_NW][STAGE > 4 ? 1 : TJ_MAXK][8];     // wave partials {S, P, Q, D, R3, R4, P2, -} per node (sample-split sums)
     float pmin[TB_NW];
     double red[TB_PER][TB_NV];
     TjOut out;
@@ -425,12 +426,14 @@ __device__ __forceinline__ TbSolved trajb_solve(
                         a3[q] = p3.x + p3.y; a4[q] = p4.x + p4.y;
                     }
                 }
+                if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && round == 0) dbg[980] = wall_clock64();
                 const float tI = wave_reduce8(aI);
                 const float tP = wave_reduce8(aP);
                 const float tQ = wave_reduce8(aQ);
                 const float tD = wave_reduce8(aD);
                 float t3 = 0.0f, t4 = 0.0f;
                 if (HI) { t3 = wave_reduce8(a3); t4 = wave_reduce8(a4); }
+                if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && round == 0) dbg[981] = wall_clock64();
                 // stage A straight from the registers: after the butterflies all eight lanes of a group hold
                 // their node's totals, so lane 8 s + j stores granule j of node c0 + s -- one write-through
                 // store per lane, no LDS, no workgroup barrier, and a wave's records leave as soon as THAT
@@ -472,7 +475,8 @@ __device__ __forceinline__ TbSolved trajb_solve(
         // ---- stage A: this workgroup's record of every evaluated node
         // (waves 0..3 each combine the wave partials and store ONE granule per lane -- S, S', Q, D;
         //  a lane's write-through stores go out one after the other)
-        if (!NSPLIT && wave < 4 && !dead && lane < Ke) {
+        if constexpr (!NSPLIT) {
+        if (wave < 4 && !dead && lane < Ke) {
             double dq = 0.0;
 #pragma unroll
             for (int w = 0; w < TB_NW; ++w) dq += (double)sh.wp[w][lane][wave];
@@ -495,6 +499,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
                 __hip_atomic_store(rec + 5 + wave, ((unsigned long long)tag << 32) | __float_as_uint(hq),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
         }
         TB_STAMP();   // stage A stored
         // ---- stage B: workgroup k < Ke adds node k's records and publishes the total

@@ -162,6 +162,9 @@ with torch.cuda.stream(side):
         print("  slope  :", np.array(ee & 0xFFFFFFFF, np.uint32).view(np.float32)[:24])
         cs = full[990:996].astype(np.int64)
         print("recurrence wave [entry, prepared, chain, trust/tail, acceptance, out] us:", [round(float(v - cs[0]) / 100.0, 2) for v in cs])
+        if int(full[980]) > 0:
+            print("sums of workgroup 0 / wave 0: arithmetic done at", round(float(int(full[980]) - int(st[0])) / 100.0, 2),
+                  "butterflies done at", round(float(int(full[981]) - int(st[0])) / 100.0, 2), "us since kernel start")
         if int(full[961]) > 0:
             print(f"shader clock in the E-step kernel: {int(full[960]) / int(full[961]) * 0.1:.2f} GHz "
                   f"({int(full[960])} cycles in {int(full[961]) / 100.0:.2f} us)")
