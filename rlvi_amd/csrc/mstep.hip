@@ -414,6 +414,17 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
     // 11.15 -> 10.5 us per launch at 65 536 x 100 (hold 4.0 us; 3.0 and 6.0 us are both slower than none).
     const unsigned long long t_begin = hold_ticks > 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
+    // CUWIDE (WPB == 16: ONE workgroup per CU, all of its 16 waves): a workgroup barrier right behind the ISSUE
+    // of a wave's tile loads -- no wave of the CU sends a store into the CU's memory pipeline before every wave
+    // of the CU has its loads in it.  Stamps (tools/mstep_stamps.py) show why that is the moment that counts:
+    // the issue of a CU's loads is back-pressured by what the memory system returns -- its last wave issues at
+    // 3.6-4.3 us at 65 536 x 100 -- and the first finished waves' stores (from 1.8 us on) queue in front of
+    // those loads.  The barrier releases the CU when its last load is in flight: 11.85 -> 10.9 us HBM-cold,
+    // 9.5 -> 9.3 us from the Infinity Cache (no estimate of any rate: the data decides), 15.0 -> 13.3 at x 128.
+    // (The launcher takes this form only when no wave has a second tile and the grid fills at least four
+    //  fifths of the CUs; a wave without a tile only joins the barrier.)
+    constexpr bool CUWIDE = WPB == 16;
+    if (CUWIDE && (int64_t)blockIdx.x * WPB + wave >= nfull) __syncthreads();
     for (int64_t t = (int64_t)blockIdx.x * WPB + wave; t < nfull; t += tstride) {
         const int64_t row_base = t * R;
         // ---- A
@@ -446,6 +457,11 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
         for (int i = 0; i < NI; ++i)
             stg[i] = __builtin_nontemporal_load(reinterpret_cast<const vu4 *>(src + dma_off[i]));
         RLVI_STAMP(1);
+        if (CUWIDE) {
+            __builtin_amdgcn_sched_barrier(0);       // (the loads are issued, THEN the barrier)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         ix = idx != nullptr ? ix : row_base + sub;
         if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
         if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
@@ -673,7 +689,37 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         if (grad == nullptr || (nfull > nb * WPB && gen_ticks <= 0 && hold_ticks < 0)) hold_ticks = 0;
         if (hold_ticks < 0)
             hold_ticks = mstep_hold_ticks((double)(nfull < nb * WPB ? nfull : nb * WPB) * (double)wtile_bytes);
-        if (kact == KMAX)
+        bool cuwide_done = false;
+        if constexpr (G == 4 && V * sizeof(T) == 16) {
+            constexpr int WPB16 = 16;
+            int64_t nb16 = (nfull + WPB16 - 1) / WPB16;
+            // (a caller that has hinted HBM-resident logits gets the four-wave workgroups with the timed hold:
+            //  10.65 against 10.95 us -- the timed hold separates the phases chip-wide, the barrier per CU)
+            if (tune_get("RLVI_MSTEP_CUWIDE", 1) && grad != nullptr && hold_ticks == 0 && nb16 <= cus &&
+                nb16 * 5 >= (int64_t)cus * 4 && nb16 <= MSTEP_MAX_BLOCKS) {
+                const size_t lds16 = (size_t)WPB16 * SKB * 1024;
+                auto go = [&](auto kern) {
+                    static int attr_dev = -1;      // (> 64 KiB of dynamic LDS: asked for once per kernel and device)
+                    int cur_dev = 0;
+                    if (hipGetDevice(&cur_dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+                    if (attr_dev != cur_dev) {
+                        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+                        if (e != hipSuccess) return (int)e;
+                        attr_dev = cur_dev;
+                    }
+                    return launch(kern, dim3((unsigned)nb16), dim3(WPB16 * WAVE), lds16, st, logits, labels, idx,
+                                  weights, residuals, N, nfull, C, inv_scale, grad, part, status, accum, inv_rows100,
+                                  hold_ticks, 0);
+                };
+                rc = kact == KMAX ? go(mstep_wave_kernel<T, V, G, KMAX, WPB16, true>)
+                                  : go(mstep_wave_kernel<T, V, G, KMAX, WPB16, false>);
+                nb = nb16;
+                cuwide_done = true;
+            }
+        }
+        if (cuwide_done) {
+        } else if (kact == KMAX)
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, true>, dim3((unsigned)nb), dim3(WPB * WAVE),
                         lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
                         part, status, accum, inv_rows100, hold_ticks, gen_ticks);

@@ -196,13 +196,16 @@ def test_mstep_bench_size_properties_and_oracle(gpu, oracle):
     assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
 
 
-def test_mstep_reads_then_writes_hold_changes_no_bit(gpu):
-    """ops.hint_logits_from_hbm(True): a one-tile-per-wave launch holds its gradient stores until its reads
-    have had their time (mstep.hip).  It is a matter of WHEN the stores leave, never of what they carry:
-    gradient, residuals and the batch scalars are bit-identical with and without the hint, also for an
-    explicit, absurdly long hold."""
+def test_mstep_reads_then_writes_forms_change_no_bit(gpu):
+    """The M-step separates its reads from its writes in two ways (mstep.hip): by default a launch that fills the
+    chip with one tile per wave runs 16-wave workgroups with a barrier behind the issue of the tile loads; with
+    ops.hint_logits_from_hbm(True) four-wave workgroups hold their stores for the read time of the block.  Both
+    are a matter of WHEN the stores leave, never of what they carry: gradient and residuals are bit-identical
+    between the plain four-wave form, the 16-wave form, the timed hold and an absurdly long hold; the batch
+    scalars agree to fp64 summation order (the per-workgroup records group the rows differently)."""
     torch, ops, dev = gpu
     from rlvi_amd import _lib
+    L = _lib.load()
     B, C = 65536, 100
     d = synth.mstep_inputs(B, C, seed=21)
     z = torch.from_numpy(d["logits"]).to(dev)
@@ -210,16 +213,20 @@ def test_mstep_reads_then_writes_hold_changes_no_bit(gpu):
     w = torch.from_numpy(d["weights"]).to(dev)
     got = []
     try:
-        for knob in (0, -1, 1500):
-            _lib.check(_lib.load().rlvi_tune_set(b"RLVI_MSTEP_HOLD", knob), "tune")
+        for cuwide, hold in ((0, 0), (1, 0), (0, -1), (0, 1500)):
+            _lib.check(L.rlvi_tune_set(b"RLVI_MSTEP_CUWIDE", cuwide), "tune")
+            _lib.check(L.rlvi_tune_set(b"RLVI_MSTEP_HOLD", hold), "tune")
             res = torch.zeros(B, device=dev)
             out, grad = ops.mstep_fwd_bwd(z, lab, idx, w, res)
             torch.cuda.synchronize()
             got.append((out.cpu().numpy(), grad.cpu().numpy(), res.cpu().numpy()))
     finally:
+        _lib.check(L.rlvi_tune_set(b"RLVI_MSTEP_CUWIDE", 1), "tune")
         ops.hint_logits_from_hbm(False)
     for o, g, r in got[1:]:
-        assert np.array_equal(o, got[0][0]) and np.array_equal(g, got[0][1]) and np.array_equal(r, got[0][2])
+        assert np.array_equal(g, got[0][1]) and np.array_equal(r, got[0][2])
+        np.testing.assert_allclose(o, got[0][0], rtol=1e-6)
+    assert np.array_equal(got[2][0], got[0][0]) and np.array_equal(got[3][0], got[0][0])   # same workgroups: same sums
     assert dev_status(ops, dev) == 0
 
 
