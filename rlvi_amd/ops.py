@@ -141,9 +141,10 @@ def hint_logits_from_hbm(flag=True):
     True: the [B, C] block streams from HBM -- it is larger than the Infinity Cache, or (bench.py) one of
     many blocks touched in rotation.  A one-tile-per-wave launch of 12 MB and more then holds its gradient
     stores until its reads have had their time at the HBM read rate (reads first, then writes, chip-wide:
-    mstep.hip), 11.8 -> 10.7 us at 65 536 x 100.  False (the default): the block was just written by the
-    model's last layer and is served by the cache -- what train_rlvi sees -- where the same hold would cost
-    time (9.4 -> 10.3 us)."""
+    mstep.hip), 11.8 -> 10.7 us at 65 536 x 100.  False (the default): nothing is assumed -- a chip-filling
+    launch separates its reads from its writes per CU with a barrier behind the issue of its loads (10.9 us
+    from HBM, 9.3 us from the cache); the timed hold would cost time on a block that the model's last layer
+    has just written and the cache serves (9.4 -> 10.3 us), which is what train_rlvi sees."""
     _lib.check(_lib.load().rlvi_tune_set(b"RLVI_MSTEP_HOLD", -1 if flag else 0), "rlvi_tune_set")
 
 
