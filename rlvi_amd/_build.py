@@ -38,7 +38,10 @@ def stale():
 
 def build(force=False, verbose=False, extra_flags=None, lib=LIB):
     extra = list(extra_flags or shlex.split(os.environ.get("RLVI_EXTRA_FLAGS", "")))
-    objdir = OBJ if lib == LIB and not extra else OBJ + "_" + str(abs(hash(tuple(extra))) % 10**8)
+    # (variant builds -- extra flags, tools/build_variants.py -- get an object directory named after their flags:
+    #  a stable digest, so that rebuilding a variant reuses its directory instead of leaving a new one behind)
+    import hashlib
+    objdir = OBJ if lib == LIB and not extra else OBJ + "_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10]
     os.makedirs(objdir, exist_ok=True)
     hdrs = headers()
     jobs = []
