@@ -30,7 +30,8 @@
 namespace rlvi {
 
 // (one-sample slices at 256 threads: three waves per SIMD -- at most 168 registers -- so that the occupancy
-//  query proves 512 workgroups co-resident and the full 256 + 1 grid keeps its one-sample slices)
+//  query proves 512 workgroups co-resident: the full 256-workgroup grid keeps its one-sample slices even when two
+//  processes share the device)
 // (measured and not kept, round 3: 512-thread workgroups whose second four waves hold no samples and only take
 //  their share of the nodes in the sums, as the in-batch kernel's spare waves do -- 22.1 against 21.9 us per step)
 #ifndef RLVI_TB_MINW
@@ -108,7 +109,6 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     // from 1e6 on (whole step / eager call, hipGraph): 512 threads only for slices beyond 4096
     const int blk = tune_get("RLVI_TB_BLOCK", 0);
     unsigned long long *dbg = (debug && !dry_run) ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
-    const int extra = 0;      // (the epoch-end reduction rides on workgroup G - 1)
     const int64_t Nall = sharded ? n_all : N;
     PeerTable *pt = (sharded && !dry_run) ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
     const int verify = tune_get("RLVI_TJ_VERIFY", 0);      // 1: always run the verification round
@@ -116,7 +116,7 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     // The exchanging workgroups wait for each other, so all of them (and the reduction workgroup) must
     // be resident at once: a geometry (E samples per thread, B threads) runs on G = min(TB_G, what
     // coop_cap proves co-resident for THIS instantiation on this device -- 1/S of it when S processes
-    // share the device --, less the reduction workgroup) workgroups and is admitted when G >= TJ_MAXK
+    // share the device) workgroups and is admitted when G >= TJ_MAXK
     // (node k is reduced by workgroup k) and the slice N/G fits E x B.  The candidates are tried in the
     // order of their slice length, so with the whole device available the choice is the one measured
     // fastest (the smallest slice that holds N/256), and with fewer co-resident workgroups a fatter
@@ -125,11 +125,11 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     do {                                                                                          \
         if (launched) break;                                                                      \
         auto kern = estep_trajb_kernel<E_, B_>;                                                   \
-        int G = coop_cap(kern, B_) - extra;                                                       \
+        int G = coop_cap(kern, B_);                                                               \
         if (G > TB_G) G = TB_G;                                                                   \
         if (G >= TJ_MAXK && (N + G - 1) / G <= (int64_t)(E_) * (B_)) {                            \
             if (!dry_run)                                                                         \
-                *rc = launch(kern, dim3((unsigned)(G + extra)), dim3(B_), 0, st, res, wts, N, tol, maxiter, \
+                *rc = launch(kern, dim3((unsigned)G), dim3(B_), 0, st, res, wts, N, tol, maxiter,           \
                              out_iters, trace, ws, mstep_out, mstep_scale, dbg, G, Nall, pt, verify); \
             else                                                                                  \
                 *rc = 0;                                                                          \
