@@ -69,6 +69,8 @@ def test_ops_refuse_cpu_tensors():
         ops.estep_deep(torch.zeros(4), torch.ones(4))
     with pytest.raises(_lib.RlviError):
         ops.fn_threshold(torch.ones(4))
+    with pytest.raises(_lib.RlviError, match="no CPU fallback"):
+        ops.MStepLoop(torch.ones(4), torch.zeros(4))          # the training loop's launcher: same rule
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -58,6 +58,9 @@ def _worker(rank, world, port, mode, q):
             q.put((rank, "ok"))
             return
         assert np.array_equal(res.numpy(), res1), "replicas differ from the single-device vector"
+        # host helpers of round 3 on a box without a GPU: rank 0's value everywhere; no device to share
+        assert rdist.rank0_value(10.0 + rank) == 10.0
+        assert rdist.declare_device_sharing() == 1 and rdist.declare_device_sharing() == 1
         # the per-rank losses and logit gradients SUM to the single-device ones
         t = torch.tensor([float(out["loss"]), float(out["prec1"]) * (hi - lo) / 100.0], dtype=torch.float64)
         rdist.reduce_scalars(t)
