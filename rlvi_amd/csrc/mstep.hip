@@ -685,10 +685,23 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         // caller knows which case it is in, the kernel does not (a per-CU barrier between reads and writes
         // -- 16-wave workgroups -- was built to let the data decide: no gain cold, 9.4 -> 10.1 us warm).
         int hold_ticks = tune_get("RLVI_MSTEP_HOLD", 0);
-        const int gen_ticks = tune_get("RLVI_MSTEP_GEN", 0);
-        if (grad == nullptr || (nfull > nb * WPB && gen_ticks <= 0 && hold_ticks < 0)) hold_ticks = 0;
-        if (hold_ticks < 0)
-            hold_ticks = mstep_hold_ticks((double)(nfull < nb * WPB ? nfull : nb * WPB) * (double)wtile_bytes);
+        int gen_ticks = tune_get("RLVI_MSTEP_GEN", -1);      // ticks between the holds of successive tile generations
+        const int64_t waves = nb * WPB;
+        const double gen_bytes = (double)(nfull < waves ? nfull : waves) * (double)wtile_bytes;
+        if (nfull > waves && hold_ticks < 0 && gen_ticks < 0) {
+            // several tiles per wave under the caller's HBM hint: one hold per GENERATION of tiles, the
+            // generations one read + one write of their bytes at the mixed rate apart (2 x 26.2 MB: 9.0 us).
+            // Only where it was measured to pay (tools/sweep_gen.sh): fp32, two to four FULL generations
+            // (65 536 x 100 per generation: 21.8 -> 20.0 us at two, 30.6 -> 29.3 at three, 39.8 -> 39.0 at four;
+            // five gain or lose a per cent with the spacing, a half-filled last generation or eight lose)
+            const int64_t gens = nfull / waves;
+            gen_ticks = (sizeof(T) == 4 && nfull % waves == 0 && gens >= 2 && gens <= 4 && gen_bytes >= 12.0e6)
+                            ? (int)(2.0 * gen_bytes / 5.76e6 * 100.0) : 0;
+        }
+        if (gen_ticks < 0) gen_ticks = 0;
+        if (grad == nullptr || (nfull > waves && gen_ticks <= 0 && hold_ticks < 0)) hold_ticks = 0;
+        if (hold_ticks < 0) hold_ticks = mstep_hold_ticks(gen_bytes);
+        if (hold_ticks == 0) gen_ticks = 0;
         bool cuwide_done = false;
         if constexpr (G == 4 && V * sizeof(T) == 16) {
             constexpr int WPB16 = 16;
