@@ -239,6 +239,9 @@ __device__ __forceinline__ TbSolved trajb_solve(
         }
     };
     stage_slice(true);
+#if RLVI_STAMPS
+    if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { dbg[983] = __builtin_amdgcn_s_memtime(); dbg[985] = wall_clock64(); }
+#endif
     // (node-split: the workgroup's minimum is known to every wave from here on -- each wave publishes the
     //  records of its own nodes itself, the minimum included)
     float wmin_all = __builtin_inff();
@@ -426,7 +429,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
                         a3[q] = p3.x + p3.y; a4[q] = p4.x + p4.y;
                     }
                 }
-                if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && round == 0) dbg[980] = wall_clock64();
+                if ((RLVI_STAMPS && dbg != nullptr) && blockIdx.x == 0 && threadIdx.x == 0 && round == 0) { dbg[980] = wall_clock64(); dbg[984] = __builtin_amdgcn_s_memtime(); }
                 const float tI = wave_reduce8(aI);
                 const float tP = wave_reduce8(aP);
                 const float tQ = wave_reduce8(aQ);

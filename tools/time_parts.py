@@ -165,6 +165,9 @@ with torch.cuda.stream(side):
         if int(full[980]) > 0:
             print("sums of workgroup 0 / wave 0: arithmetic done at", round(float(int(full[980]) - int(st[0])) / 100.0, 2),
                   "butterflies done at", round(float(int(full[981]) - int(st[0])) / 100.0, 2), "us since kernel start")
+        if int(full[984]) > 0 and int(full[980]) > int(full[985]):
+            print(f"   shader clock from the staged slice to the end of the sums' arithmetic: "
+                  f"{(int(full[984]) - int(full[983])) / (int(full[980]) - int(full[985])) * 0.1:.2f} GHz")
         if int(full[961]) > 0:
             print(f"shader clock in the E-step kernel: {int(full[960]) / int(full[961]) * 0.1:.2f} GHz "
                   f"({int(full[960])} cycles in {int(full[961]) / 100.0:.2f} us)")
