@@ -202,16 +202,21 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
             // two register sets, two steps per trip: the operands of step k + 1 are asked for BEFORE the
             // arithmetic of step k, so the LDS latency (~100 clocks) runs beside a step instead of in front of
             // every one (written out by hand: with one set and a copy the compiler rotates the loop and the
-            // read lands at the top of the step that needs it)
-            // (a step leaves {r_k, avg_k} in the node's slot of the operand table -- one LDS store -- and the
-            //  lanes fetch their own node's pair after the loop: a compare and two selects less per step)
+            // read lands at the top of the step that needs it).  A lone wave issues one vector instruction per
+            // ~6 clocks whatever it depends on (tools/lab/valu_rate.hip), so a step costs its instruction
+            // count (52 ns): it carries avg and 1 / (1 - avg) instead of r = avg / (1 - avg), takes
+            // dr = avg * inv - r' as ONE fused multiply-add and leaves {avg_k, inv_k} in the node's slot of the
+            // operand table -- one LDS store, no compare / selects; the lanes form their own
+            // r_k = avg_{k-1} * inv_{k-1} after the loop
+            float ap = r, ip = 1.0f;                                   // r_0 = ap * ip exactly
             auto chain_step = [&](int step, const float4 &ca, const float2 &cb) {
-                const float dr = r - ca.x;
+                const float dr = fmaf(ap, ip, -ca.x);                  // r_k - r'_k
                 const float dr2 = dr * dr;
                 const float lo2 = fmaf(dr, ca.z, ca.y), hi2 = fmaf(dr, cb.x, -ca.w);
                 const float avg = fmaf(dr2 * dr2, -cb.y, fmaf(dr2, hi2, lo2));
-                *reinterpret_cast<float2 *>(out.coef[step] + 6) = make_float2(r, avg);
-                r = avg * __builtin_amdgcn_rcpf(1.0f - avg);                              // (:31)
+                const float inv = __builtin_amdgcn_rcpf(1.0f - avg);   // (:31)
+                *reinterpret_cast<float2 *>(out.coef[step] + 6) = make_float2(avg, inv);
+                ap = avg; ip = inv;
             };
             float4 a0v = *reinterpret_cast<const float4 *>(out.coef[0]);
             float2 b0v = *reinterpret_cast<const float2 *>(out.coef[0] + 4);
@@ -230,10 +235,15 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
             if (step < steps) chain_step(step, a0v, b0v);
             __builtin_amdgcn_wave_barrier();
             if (lane < steps) {
-                const float2 ra = *reinterpret_cast<const float2 *>(out.coef[lane] + 6);
-                rnew_l = ra.x;
-                avg_l = ra.y;
+                avg_l = out.coef[lane][6];
+                if (lane > 0) {
+                    const float2 pv = *reinterpret_cast<const float2 *>(out.coef[lane - 1] + 6);
+                    rnew_l = pv.x * pv.y;                              // r_k = avg_{k-1} / (1 - avg_{k-1})
+                } else {
+                    rnew_l = r;
+                }
             }
+            r = ap * ip;                                               // (the r after the last step, as before)
         } else {
 #pragma unroll 1
             for (int step = 0; step < steps; ++step) {
