@@ -196,17 +196,20 @@ def test_mstep_bench_size_properties_and_oracle(gpu, oracle):
     assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
 
 
-def test_mstep_reads_then_writes_forms_change_no_bit(gpu):
+@pytest.mark.parametrize("B", [65536, 57365])
+def test_mstep_reads_then_writes_forms_change_no_bit(gpu, oracle, B):
     """The M-step separates its reads from its writes in two ways (mstep.hip): by default a launch that fills the
     chip with one tile per wave runs 16-wave workgroups with a barrier behind the issue of the tile loads; with
     ops.hint_logits_from_hbm(True) four-wave workgroups hold their stores for the read time of the block.  Both
     are a matter of WHEN the stores leave, never of what they carry: gradient and residuals are bit-identical
     between the plain four-wave form, the 16-wave form, the timed hold and an absurdly long hold; the batch
-    scalars agree to fp64 summation order (the per-workgroup records group the rows differently)."""
+    scalars agree to fp64 summation order (the per-workgroup records group the rows differently).  57 365 rows:
+    3585 full tiles and five trailing rows -- the last 16-wave workgroup has one wave with a tile and fifteen that
+    only join the barrier."""
     torch, ops, dev = gpu
     from rlvi_amd import _lib
     L = _lib.load()
-    B, C = 65536, 100
+    C = 100
     d = synth.mstep_inputs(B, C, seed=21)
     z = torch.from_numpy(d["logits"]).to(dev)
     lab, idx = torch.from_numpy(d["labels"]).to(dev), torch.from_numpy(d["idx"]).to(dev)
@@ -228,6 +231,11 @@ def test_mstep_reads_then_writes_forms_change_no_bit(gpu):
         np.testing.assert_allclose(o, got[0][0], rtol=1e-6)
     assert np.array_equal(got[2][0], got[0][0]) and np.array_equal(got[3][0], got[0][0])   # same workgroups: same sums
     assert dev_status(ops, dev) == 0
+    r0 = np.zeros(B, np.float32)
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], r0)
+    np.testing.assert_allclose(got[1][2], r0, rtol=REL, atol=1e-6)
+    diff = got[1][1].astype(np.float64) - ref["grad"]
+    assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
 
 
 def test_mstep_accumulate_and_epoch_end(gpu, oracle):
