@@ -651,8 +651,12 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
     constexpr int R = WAVE / G;
     constexpr int WPB = 4;                          // waves per workgroup of the wave-tile form
     const int cus = device_info().cus;
-    // form: 1 = wave tiles through LDS (dense rows), 0 = register rows everywhere
-    const int form = tune_get("RLVI_MSTEP_FORM", 1);
+    // form: 1 = wave tiles through LDS (dense rows), 0 = register rows everywhere; -1 (default): wave tiles
+    // once the launch has more than two waves per CU (512 tiles) -- below that a call is one wave's latency
+    // long, and global -> registers -> global is shorter than the trip through LDS (tools/sweep_small.sh:
+    // 4096 x 10 3.4 -> 3.1 us, 4096 x 100 4.05 -> 3.7; 16 384 x 100 the other way, 5.2 against 5.7)
+    int form = tune_get("RLVI_MSTEP_FORM", -1);
+    if (form < 0) form = (B + R - 1) / R > 512 ? 1 : 0;
     char *base = static_cast<char *>(ws);
     double *part = reinterpret_cast<double *>(base + WS_PART_OFF);
     int32_t *status = reinterpret_cast<int32_t *>(base);
@@ -788,13 +792,20 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
     // V = 1) keep the 64-row tile and four lanes per row, each lane holding up to 32 / V short
     // vectors: 11.6 us instead of 20.0 at 65 536 x 101 fp32 (the 16-lane form spends its time in
     // per-element address arithmetic and DPP steps)
-    if constexpr (V * sizeof(T) < 16) {
-        if (gsel > 4 && C <= 128 && !force_g) {
+    // -- only for launches of at least two such tiles per SIMD (fp32 C = 101: 8.6 against 9.4 us at 32 768
+    // rows, 7.2 against 5.8 at 16 384, 5.7 against 3.1 at 1024), and never for single 2-byte elements (bf16
+    // C = 101: one ds_read_u16 per element, 27.5 against 14.3 us at 65 536 rows, 9.2 against 3.1 at 1024)
+    if constexpr (V * sizeof(T) < 16 && V * sizeof(T) > 2) {
+        if (gsel > 4 && C <= 128 && !force_g && B >= 16 * 2048) {
             const int k4 = (nv + 3) / 4;
             if (k4 <= 16) RLVI_CASE(4, 16);
             if constexpr (V == 1) RLVI_CASE(4, 32);
         }
     }
+    // a launch of less than one wave per SIMD is as long as ONE wave's instruction stream (a lone wave issues
+    // an instruction every ~6 clocks): twice the lanes per row halve it (tools/sweep_small.sh: 4096 x 10
+    // 3.65 -> 3.3 us, 4096 x 100 4.4 -> 4.05, 1024 x 101 3.35 -> 3.1; from 1024 waves on the wider tile wins)
+    if (!force_g && gsel < 64 && (nv + gsel - 1) / gsel >= 2 && (B * gsel + 63) / 64 < 1024) gsel *= 2;
     const int k = (nv + gsel - 1) / gsel;
     if (k > 8) return RLVI_E_LIMIT;
     switch (gsel) {
@@ -810,8 +821,8 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
             if (k == 6) RLVI_CASE(4, 6);
             if (k == 7) RLVI_CASE(4, 7);
             RLVI_CASE(4, 8);
-        case 8: if (k <= 4) RLVI_CASE(8, 4); RLVI_CASE(8, 8);
-        case 16: if (k <= 4) RLVI_CASE(16, 4); RLVI_CASE(16, 8);
+        case 8: if (k <= 2) RLVI_CASE(8, 2); if (k <= 4) RLVI_CASE(8, 4); RLVI_CASE(8, 8);
+        case 16: if (k <= 2) RLVI_CASE(16, 2); if (k <= 4) RLVI_CASE(16, 4); RLVI_CASE(16, 8);
         case 32: if (k <= 4) RLVI_CASE(32, 4); RLVI_CASE(32, 8);
         default: if (k <= 4) RLVI_CASE(64, 4); RLVI_CASE(64, 8);
     }

@@ -1109,19 +1109,26 @@ def test_small_loss_baselines_golden(key, golden, gpu):
     t = torch.from_numpy(d1["labels"]).to(dev)
 
     def close(a, ref):
-        np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-5, atol=max(1e-6 * np.abs(ref).max(), 2.0 ** -24))
+
+    def loss_close(a, ref):
+        # the selected rows are the SMALLEST losses: log(sum exp(z - max)) with the sum = 1 + 1e-5, where one
+        # rounding of the fp32 sum (2^-24, whichever order the terms are added in -- the reference's own order
+        # included) is half a per cent of the loss: relative 1e-5 plus that one rounding (the same for the
+        # label column's gradient p - 1 in `close`)
+        assert abs(float(a) - float(ref)) <= REL * abs(float(ref)) + 2.0 ** -24
 
     z = torch.from_numpy(d1["logits"]).to(dev).requires_grad_(True)
     loss = usdnl.loss_fn(z, t, fr)
     loss.backward()
-    assert abs(float(loss) - float(g[key + "/usdnl_loss"])) <= REL * abs(float(g[key + "/usdnl_loss"]))
+    loss_close(loss.detach(), g[key + "/usdnl_loss"])
     close(z.grad, g[key + "/usdnl_grad"])
     z1 = torch.from_numpy(d1["logits"]).to(dev).requires_grad_(True)
     z2 = torch.from_numpy(d2["logits"]).to(dev).requires_grad_(True)
     l1, l2 = cot.loss_coteaching(z1, z2, t, fr, None)
     (l1 + l2).backward()
-    assert abs(float(l1) - float(g[key + "/cot_loss1"])) <= REL * abs(float(g[key + "/cot_loss1"]))
-    assert abs(float(l2) - float(g[key + "/cot_loss2"])) <= REL * abs(float(g[key + "/cot_loss2"]))
+    loss_close(l1.detach(), g[key + "/cot_loss1"])
+    loss_close(l2.detach(), g[key + "/cot_loss2"])
     close(z1.grad, g[key + "/cot_grad1"])
     close(z2.grad, g[key + "/cot_grad2"])
 
@@ -1165,7 +1172,9 @@ def test_small_loss_baselines_train_loops(gpu):
     for which in ("usdnl", "coteaching"):
         # co-teaching's loss carries the reference's extra 1/num_remember (train_coteaching.py:35):
         # the same SGD step needs a learning rate ~num_remember times larger
-        lr = 0.1 if which == "usdnl" else 0.1 * 160
+        # (0.05: at 0.1 one run in ten loses the network to a loss spike in epoch 3 -- every device result of
+        #  such a run still matches stock torch ops batch by batch, tools/lab/dbg_usdnl.py)
+        lr = 0.05 if which == "usdnl" else 0.05 * 160
         m1 = driver.LeNet().to(dev)
         o1 = torch.optim.SGD(m1.parameters(), lr=lr, momentum=0.9)
         m2 = driver.LeNet().to(dev)
