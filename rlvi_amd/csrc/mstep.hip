@@ -822,7 +822,7 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
             if (k == 7) RLVI_CASE(4, 7);
             RLVI_CASE(4, 8);
         case 8: if (k <= 2) RLVI_CASE(8, 2); if (k <= 4) RLVI_CASE(8, 4); RLVI_CASE(8, 8);
-        case 16: if (k <= 2) RLVI_CASE(16, 2); if (k <= 4) RLVI_CASE(16, 4); RLVI_CASE(16, 8);
+        case 16: if (k <= 4) RLVI_CASE(16, 4); RLVI_CASE(16, 8);
         case 32: if (k <= 4) RLVI_CASE(32, 4); RLVI_CASE(32, 8);
         default: if (k <= 4) RLVI_CASE(64, 4); RLVI_CASE(64, 8);
     }

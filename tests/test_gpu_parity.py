@@ -95,6 +95,46 @@ def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     assert dev_status(gpu[1], gpu[2]) == 0
 
 
+@pytest.mark.parametrize("B,C,dtype", [
+    (70003, 10, "f32"),      # one lane per row, wave tiles (>= 1024 waves: no doubling of the lanes)
+    (40001, 101, "f32"),     # rows not a multiple of 16 bytes, >= 32 768 rows: four lanes x 32 single elements
+    (33001, 102, "f32"),     # ... x 16 two-element vectors
+    (20005, 100, "f32"),     # four lanes per row, four-wave workgroups (too few tiles for the 16-wave form)
+    (9001, 100, "f32"),      # eight lanes per row (doubled), wave tiles (> 512 tiles)
+    (70003, 7, "f32"),       # single elements, one lane per row
+    (1024, 101, "bf16"),     # cfg5: 32 lanes per row, register rows
+    (8195, 101, "bf16"),     # 16 lanes per row, register rows (a 4-row tile is not a multiple of 16 bytes)
+    (70003, 101, "bf16"),
+    (1029, 104, "bf16"),     # eight lanes x two 8-element vectors, register rows
+    (20005, 104, "bf16"),    # four lanes per row, wave tiles
+    (3000, 200, "bf16"),
+])
+def test_mstep_dispatch_by_launch_size_vs_oracle(B, C, dtype, gpu, oracle):
+    """The launcher picks lanes per row and kernel form by the SIZE of the launch (mstep.hip dispatch_gk /
+    launch_mstep: fewer than 1024 waves -> twice the lanes per row; up to 512 tiles -> register rows; the
+    four-lane tile for unaligned rows only from 32 768 rows on): every branch against the oracle at a row count
+    that selects it, ragged tails included.  bf16: the oracle is fed the bf16-rounded logits as fp32 and its
+    gradient rounded to bf16 (storage precision), as in test_mstep_bf16_golden."""
+    torch, ops, dev = gpu
+    d = synth.mstep_inputs(B, C, N=B + 17, seed=B + C, zero_frac=0.1)
+    if dtype == "bf16":
+        d["logits"] = torch.from_numpy(d["logits"]).to(torch.bfloat16).float().numpy()
+    out, res = run_mstep(gpu, d, dtype=dtype)
+    r0 = d["residuals"].copy()
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], r0)
+    np.testing.assert_allclose(res, r0, rtol=REL, atol=1e-6)
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= REL * abs(float(ref["loss"]))
+    assert float(out["hits"]) == float(round(float(ref["prec1"]) * B / 100.0))
+    if dtype == "bf16":
+        rg = torch.from_numpy(ref["grad"].astype(np.float32)).to(torch.bfloat16).float().numpy()
+        np.testing.assert_allclose(out["grad"], rg, rtol=2 ** -7, atol=1e-7)
+    else:
+        diff = out["grad"].astype(np.float64) - ref["grad"]
+        assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+        assert np.abs(diff).max() <= 1e-6
+    assert dev_status(ops, dev) == 0
+
+
 def test_mstep_strided_rows_and_forward_only(gpu, oracle):
     torch, ops, dev = gpu
     B, C, LD = 96, 100, 128
