@@ -228,6 +228,20 @@ __device__ __forceinline__ uint32_t one_minus_u(float p) {
     return (uint32_t)__float2uint_rn((1.0f - p) * 16777216.0f);
 }
 
+// Wave totals in 32-bit steps.  A 64-bit butterfly step is two DPP moves and a carry chain (or a 64-bit
+// compare and two selects); these reductions run on waves that have a SIMD to themselves, where every
+// instruction costs its ~6 clocks: counts (< 2^31) and keys (<= 0x3F800000, 0xFFFFFFFF = none) are 32-bit
+// values, and a sum below 2^40 is two 32-bit sums of its low 20 bits and the rest.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)wave_sum((int)v); }
+__device__ __forceinline__ uint32_t wave_min_key(uint32_t v) {
+    const int r = wave_min((int)(v > 0x7FFFFFFFu ? 0x7FFFFFFFu : v));
+    return r == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)r;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u40(unsigned long long v) {
+    const uint32_t lo = wave_sum_u32((uint32_t)v & 0xFFFFFu), hi = wave_sum_u32((uint32_t)(v >> 20));
+    return ((unsigned long long)hi << 20) + lo;
+}
+
 struct ThqHist {                       // one histogram: what a workgroup publishes / what comes back
     unsigned long long sum[THR_BINS];
     uint32_t cnt[THR_BINS];
@@ -291,7 +305,11 @@ __device__ __forceinline__ bool thq_load(gu64 *p, uint32_t tag, uint32_t &cnt, u
 // pt != nullptr (sharded over several GPUs): the bin's publishing wave first pushes this rank's totals
 // into every rank's inbox, adds up what all ranks pushed (integers: exact, order-free) and publishes the
 // global totals; ptag numbers the sharded exchanges of the group (rlvi_trajb.h uses the same counter).
-template <int NH>
+// COARSE0: histogram [0] holds the three coarse bins of a warm call's first digit (and the out-of-range
+// count in bin 255) -- only those four records are published, gathered and read back (the other 252 would be
+// 1 MB of empty write-through records per exchange).
+__device__ __forceinline__ bool thq_coarse_bin(int bin) { return bin < 3 || bin == THR_BINS - 1; }
+template <int NH, bool COARSE0 = false>
 __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bufB, uint32_t tag,
                                              int xstep, int G, WsHeader *hdr,
                                              unsigned long long spin_ticks, unsigned long long *dbg,
@@ -318,6 +336,7 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
         } else {
             q = (thq_vu4){sh.h[hf].cnt[bin], tag, sh.h[hf].mn[bin], tag};
         }
+        if (!(COARSE0 && hf == 0) || thq_coarse_bin(bin))
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1"
                      :
                      : "v"((unsigned long long)(uintptr_t)(A + (size_t)b * NREC * XCHG4_GRANULES) + (unsigned long long)c * 16ull),
@@ -338,7 +357,10 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
             const unsigned long long t0 = wall_clock64();
             bool got[NH];
 #pragma unroll
-            for (int hf = 0; hf < NH; ++hf) got[hf] = false;
+            for (int hf = 0; hf < NH; ++hf) {
+                got[hf] = COARSE0 && hf == 0 && !thq_coarse_bin(bin);
+                c[hf] = 0u; mn[hf] = 0xFFFFFFFFu; sm[hf] = 0ull;
+            }
             for (unsigned spin = 0;; ++spin) {
                 bool all = true;
 #pragma unroll
@@ -357,9 +379,10 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
             if (timeout) { c[hf] = 0; mn[hf] = 0xFFFFFFFFu; sm[hf] = 0ull; }
-            const unsigned long long tc = wave_sum((unsigned long long)c[hf]);
-            const unsigned long long ts = wave_sum(sm[hf]);
-            const uint32_t tm = (uint32_t)wave_min((unsigned long long)mn[hf]);
+            // (a record's sum: at most 8192 keys of at most 2^24 units)
+            const unsigned long long tc = wave_sum_u32(c[hf]);
+            const unsigned long long ts = wave_sum_u40(sm[hf]);
+            const uint32_t tm = wave_min_key(mn[hf]);
             if (lane == 0) { sh.wcnt[hf * THQ_NW + wave] = tc; sh.wsum[hf * THQ_NW + wave] = ts; sh.wmin[hf * THQ_NW + wave] = tm; }
         }
         __syncthreads();
@@ -368,6 +391,7 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
             const int gq = lane & 3, rep = lane >> 2;
 #pragma unroll
             for (int hf = 0; hf < NH; ++hf) {
+                if (COARSE0 && hf == 0 && !thq_coarse_bin(bin)) continue;      // (nobody reads it)
                 unsigned long long tc = 0ull, ts = 0ull;
                 uint32_t tm = 0xFFFFFFFFu;
                 for (int w = wave; w < wave + wpb; ++w) {    // fixed order (integers: any order gives these bits)
@@ -434,7 +458,7 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
             const unsigned long long t0 = wall_clock64();
             bool got[NH];
 #pragma unroll
-            for (int hf = 0; hf < NH; ++hf) got[hf] = false;
+            for (int hf = 0; hf < NH; ++hf) got[hf] = COARSE0 && hf == 0 && !thq_coarse_bin(tid);
             for (unsigned spin = 0;; ++spin) {
                 bool all = true;
 #pragma unroll
@@ -568,9 +592,9 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         // count / smallest key of the bins >= b1 (masked block reductions), first: the global minimum
         {
             const bool up = tid >= b1;
-            const unsigned long long cw = wave_sum(up ? (unsigned long long)H.cnt[tid] : 0ull);
-            const uint32_t mw = (uint32_t)wave_min(up ? (unsigned long long)H.mn[tid] : 0xFFFFFFFFull);
-            const uint32_t gw = first ? (uint32_t)wave_min((unsigned long long)H.mn[tid]) : 0u;
+            const unsigned long long cw = wave_sum_u32(up ? H.cnt[tid] : 0u);
+            const uint32_t mw = wave_min_key(up ? H.mn[tid] : 0xFFFFFFFFu);
+            const uint32_t gw = first ? wave_min_key(H.mn[tid]) : 0u;
             if (lane == 0) { sh.wcnt[wave] = cw; sh.wmin[wave] = mw; sh.wtrue[wave] = gw; }
         }
         __syncthreads();
@@ -648,9 +672,9 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         if (coarse) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const unsigned long long wc = wave_sum((unsigned long long)cc[q]);
-                const unsigned long long wsm = wave_sum(cs[q]);
-                const uint32_t wm = (uint32_t)wave_min((unsigned long long)cm[q]);
+                const unsigned long long wc = wave_sum_u32(cc[q]);
+                const unsigned long long wsm = wave_sum_u40(cs[q]);       // (a thread: at most 32 keys)
+                const uint32_t wm = wave_min_key(cm[q]);
                 if (lane == 0) {
                     atomicAdd(&sh.h[0].sum[q], (wc << 40) | wsm);
                     atomicMin(&sh.h[0].mn[q], wm);
@@ -671,8 +695,9 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         }
         __syncthreads();
         THQ_STAMP();   // histograms built
-        ok = spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
-                  : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
+        ok = coarse ? thq_exchange<2, true>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
+             : spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
+                    : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
         ++tag; ++xstep; ++ptag;
         if (!ok) break;
         if (level == 0) {
@@ -710,10 +735,19 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
             // fit; S_base / cnt_base are the sum / count of the keys above it
             const uint32_t v = prefix;
             const unsigned long long t = one_minus_u(__uint_as_float(v));
+            // how many of v's copies still fit: the boundary of a monotone predicate on (jl, jh), 64 candidates
+            // per step -- one per lane, a ballot counts the ones that fit (exact ties and the unvisited slots'
+            // zeros come in thousands of copies: two steps instead of a dozen dependent bisections, every
+            // wave the same)
             long long jl = 0, jh = (long long)below_cnt;  // pred(S + jl t) true, pred(S + jh t) false
             while (jh - jl > 1) {
-                const long long jm = jl + ((jh - jl) >> 1);
-                if (pred(S_base + (unsigned long long)jm * t)) jl = jm; else jh = jm;
+                const long long step = (jh - jl + 63) >> 6;
+                const long long jm = jl + (long long)(lane + 1) * step;
+                const bool fits = jm < jh && pred(S_base + (unsigned long long)jm * t);
+                const long long n = (long long)__popcll(__ballot(fits));
+                const long long up = jl + (n + 1) * step;
+                jl += n * step;
+                jh = up < jh ? up : jh;
             }
             const long long j = jl;
             if (cnt_base + (unsigned long long)j == 0ull) thr = __uint_as_float(gmin);   // last_index = -1 wraps (:47-48)
@@ -723,6 +757,7 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         if (TRUNC && !(thr > prev)) thr = prev;           // threshold = max(threshold, criterion) (:102)
     }
 
+    THQ_STAMP();   // threshold known
     if (TRUNC && ok) {
         uint32_t kept = 0;
 #pragma unroll
@@ -739,7 +774,7 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         if (kept_out != nullptr) {                            // uniform: one more exchange, bin 0 carries the count
             sh.h[0].cnt[tid] = 0u; sh.h[0].mn[tid] = 0xFFFFFFFFu; sh.h[0].sum[tid] = 0ull;
             __syncthreads();
-            const unsigned long long kw = wave_sum((unsigned long long)kept);
+            const unsigned long long kw = wave_sum_u32(kept);
             if (lane == 0) atomicAdd(&sh.h[0].sum[0], kw);
             __syncthreads();
             ok = thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
