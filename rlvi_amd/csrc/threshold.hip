@@ -257,6 +257,13 @@ struct ThrState {
 constexpr size_t WS_THRSTATE_OFF = WS_TRAJ_OFF + 384;
 static_assert(384 + sizeof(ThrState) <= WS_TRAJ_BYTES, "threshold state must fit behind the trajectory state");
 
+// Key-list finish: once few keys are left inside the prefix, every workgroup publishes ITS keys (at most 16)
+// instead of another pair of 256-bin histograms, everybody reads everybody's, and the remaining digits are
+// settled locally on the complete list -- no further exchange, no guess needed.
+constexpr int THQ_LIST_CAP = 16;       // keys per workgroup (8 tagged 16-byte pairs); more: the histogram path
+constexpr uint32_t THQ_LIST_NONE = 0xFFFFFFFFu, THQ_LIST_OVER = 0xFFFFFFFEu;
+constexpr int THQ_LIST_ALL = 2048;     // keys of the complete list kept in LDS (the launcher's list_max stays below)
+
 struct ThqShared {
     ThqHist h[2];                      // [0] this digit, [1] the next digit inside the guessed bin; then the totals
     unsigned long long wsum[2 * THQ_NW];   // cross-wave scratch of the reductions
@@ -266,6 +273,9 @@ struct ThqShared {
     unsigned long long r_sum;          // results of a scan
     uint32_t r_min, r_b1;
     int dead;
+    uint32_t lcount, lover, ltotal;    // key-list finish: this workgroup's keys inside the prefix / somebody's overflow / all keys
+    uint32_t lkeys[THQ_LIST_CAP];
+    uint32_t lall[THQ_LIST_ALL];       // the complete list (every workgroup's keys inside the prefix), dense
     unsigned long long stamps[60];     // RLVI_THR_DEBUG only
 };
 
@@ -485,11 +495,92 @@ __device__ __forceinline__ bool thq_exchange(ThqShared &sh, gu64 *bufA, gu64 *bu
     return true;
 }
 
+// One hop: workgroup w stores its list (slots past its count: NONE; more than the cap: OVER in slot 0) into the
+// head of stage-A row space of this step's parity, every workgroup reads all G lists (thread t the 16-byte pairs
+// t, t + 256, ...) and appends the keys it finds to the dense list sh.lall[0 .. sh.ltotal).  Returns 0 = timed out,
+// 1 = complete, 2 = somebody overflowed (nothing else has changed: the caller goes on with histograms).
+__device__ __forceinline__ int thq_list_hop(ThqShared &sh, gu64 *bufA, uint32_t tag, int xstep, int G, WsHeader *hdr,
+                                            unsigned long long spin_ticks, unsigned long long *dbg, int &dbgi) {
+    const int tid = threadIdx.x, b = (int)blockIdx.x;
+    constexpr int NREC = 2 * THR_BINS;
+    THQ_STAMP();   // own keys compacted
+    gu64 *Lst = bufA + (size_t)(xstep & 1) * NREC * MAX_COOP_WG * XCHG4_GRANULES;
+    if (tid < THQ_LIST_CAP / 2) {
+        const uint32_t n = sh.lcount;
+        uint32_t k0 = 2 * tid < (int)n ? sh.lkeys[2 * tid] : THQ_LIST_NONE;
+        const uint32_t k1 = 2 * tid + 1 < (int)n ? sh.lkeys[2 * tid + 1] : THQ_LIST_NONE;
+        if (tid == 0 && n > (uint32_t)THQ_LIST_CAP) k0 = THQ_LIST_OVER;
+        const thq_vu4 q = {k0, tag, k1, tag};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1"
+                     :
+                     : "v"((unsigned long long)(uintptr_t)(Lst + (size_t)b * THQ_LIST_CAP) + (unsigned long long)tid * 16ull), "v"(q)
+                     : "memory");
+    }
+    // 512 / 1024 / 2048 pairs: 2 / 4 / 8 per thread, four loads in flight at a time (a pair past the end re-reads
+    // this thread's first one: always valid)
+    const int npairs = G * (THQ_LIST_CAP / 2);
+    bool timeout = false, over = false;
+    const unsigned long long t0 = wall_clock64();
+#pragma unroll
+    for (int grp = 0; grp < THQ_LIST_CAP / 8; ++grp) {
+        if (grp * 4 * THQ_BLOCK >= npairs) break;                    // (uniform)
+        unsigned long long addr[4];
+        bool want[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pr = (grp * 4 + q) * THQ_BLOCK + tid;
+            want[q] = pr < npairs;
+            addr[q] = (unsigned long long)(uintptr_t)Lst + (unsigned long long)(want[q] ? pr : tid) * 16ull;
+        }
+        thq_vu4 v[4];
+        for (unsigned spin = 0;; ++spin) {
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                         "global_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\t"
+                         "global_load_dwordx4 %3, %7, off sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                         : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
+                         : "memory");
+            bool all = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) all = all && v[q].y == tag && v[q].w == tag;
+            if (all) break;
+            if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+        }
+        if (timeout) break;
+        // this thread's keys into the dense list (any order: the histograms add integers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!want[q]) continue;
+            const uint32_t kk[2] = {v[q].x, v[q].z};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                if (kk[h2] == THQ_LIST_OVER) over = true;
+                else if (kk[h2] != THQ_LIST_NONE) {
+                    const uint32_t pos = atomicAdd(&sh.ltotal, 1u);
+                    if (pos < (uint32_t)THQ_LIST_ALL) sh.lall[pos] = kk[h2]; else over = true;
+                }
+            }
+        }
+    }
+    THQ_STAMP();   // lists read
+    if (timeout) sh.dead = 1;
+    if (over) sh.lover = 1u;
+    __syncthreads();
+    if (sh.dead != 0) {
+        if (tid == 0) atomicOr(&hdr->status, RLVI_ST_TIMEOUT);
+        return 0;
+    }
+    return sh.lover != 0u ? 2 : 1;
+}
+
 template <int E, bool TRUNC>
 __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     float *__restrict__ w, int64_t N, float alpha, float *__restrict__ thr_io,
     uint8_t *__restrict__ mask, int64_t *__restrict__ kept_out,
-    void *ws, unsigned long long *__restrict__ dbg, int use_state, int64_t Nall, PeerTable *__restrict__ pt) {
+    void *ws, unsigned long long *__restrict__ dbg, int use_state, int64_t Nall, PeerTable *__restrict__ pt,
+    int list_max) {
     // (sharded over several GPUs: N weights here, Nall over all ranks, pt the peers' inboxes; the threshold,
     //  the kept count and the warm-start key come out the same on every rank; otherwise Nall == N, pt == nullptr)
     __shared__ ThqShared sh;
@@ -632,42 +723,72 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
     // everything about the keys above.  A wrong guess costs that one exchange and restarts cold.
     int level = 0;
     bool use_warm = warm;
+    // Key-list finish (thq_list_hop): as soon as at most list_max keys are left inside the prefix (four per
+    // workgroup on average: a workgroup with more than 16 is then one in a million), the workgroups publish
+    // their keys instead of histograms and everybody settles the remaining digits on the complete list, without
+    // another exchange and whatever the last call's key was.  Same integers, same predicate, same bits.
+    bool listed = false;
 #pragma unroll 1
     while (level < 4 && ok && !all_inside) {
         const int shift = 24 - 8 * level;
+        if (!listed && level >= 1 && pt == nullptr && G > 1 && (long long)below_cnt <= (long long)list_max) {
+            if (tid == 0) { sh.lcount = 0u; sh.lover = 0u; sh.ltotal = 0u; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (have[j] && (k[j] >> (shift + 8)) == prefix) {
+                    const uint32_t pos = atomicAdd(&sh.lcount, 1u);
+                    if (pos < (uint32_t)THQ_LIST_CAP) sh.lkeys[pos] = k[j];
+                }
+            __syncthreads();
+            const int r = thq_list_hop(sh, bufA, tag, xstep, G, hdr, spin_ticks, dbg, dbgi);
+            ++tag; ++xstep;
+            THQ_STAMP();   // lists in
+            if (r == 0) { ok = false; break; }
+            listed = r == 1;
+        }
         // (the guess applies while the prefix fixed so far agrees with its leading bytes)
-        const bool spec = use_warm && level < 3 && (level == 0 || (guess >> (shift + 8)) == prefix);
+        const bool spec = !listed && use_warm && level < 3 && (level == 0 || (guess >> (shift + 8)) == prefix);
         const bool coarse = spec && level == 0;
         const uint32_t gbin = (guess >> shift) & 0xFFu;
         // ---- local histograms of the keys inside the current prefix
         sh.h[0].cnt[tid] = 0u; sh.h[0].mn[tid] = 0xFFFFFFFFu; sh.h[0].sum[tid] = 0ull;
         if (spec) { sh.h[1].cnt[tid] = 0u; sh.h[1].mn[tid] = 0xFFFFFFFFu; sh.h[1].sum[tid] = 0ull; }
-        __syncthreads();
+        __syncthreads();                                  // (the first one also waits for the slowest wave's slice: 0.6 us)
         uint32_t cc[3] = {0u, 0u, 0u}, cm[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         unsigned long long cs[3] = {0ull, 0ull, 0ull};
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool in = have[j] && (level == 0 || (k[j] >> (shift + 8)) == prefix);
+        auto hist_key = [&](bool hv, uint32_t key) {
+            const bool in = hv && (level == 0 || (key >> (shift + 8)) == prefix);
             if (in) {
-                const uint32_t bin = (k[j] >> shift) & 0xFFu;
-                const unsigned long long om = (unsigned long long)one_minus_u(__uint_as_float(k[j]));
+                const uint32_t bin = (key >> shift) & 0xFFu;
+                const unsigned long long om = (unsigned long long)one_minus_u(__uint_as_float(key));
                 if (coarse) {
                     const int c3 = bin < gbin ? 0 : (bin == gbin ? 1 : 2);
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        if (q == c3) { cc[q] += 1u; cs[q] += om; cm[q] = k[j] < cm[q] ? k[j] : cm[q]; }
+                        if (q == c3) { cc[q] += 1u; cs[q] += om; cm[q] = key < cm[q] ? key : cm[q]; }
                 } else {
                     // (count and sum in ONE LDS atomic: count << 40 | sum; a workgroup holds at most
                     //  8192 keys of at most 2^24 units each)
+                    // (measured and not kept, round 3: reducing the keys of a wave that share a bin across the
+                    //  wave and adding them by one lane -- a truncated vector's zeros put whole waves into one
+                    //  bin -- costs more than the LDS serialising the 64 lanes: 21.6 -> 22.05 us)
                     atomicAdd(&sh.h[0].sum[bin], THQ_ONE | om);
-                    atomicMin(&sh.h[0].mn[bin], k[j]);
+                    atomicMin(&sh.h[0].mn[bin], key);
                 }
                 if (spec && bin == gbin) {
-                    const uint32_t bin2 = (k[j] >> (shift - 8)) & 0xFFu;
+                    const uint32_t bin2 = (key >> (shift - 8)) & 0xFFu;
                     atomicAdd(&sh.h[1].sum[bin2], THQ_ONE | om);
-                    atomicMin(&sh.h[1].mn[bin2], k[j]);
+                    atomicMin(&sh.h[1].mn[bin2], key);
                 }
             }
+        };
+        if (listed) {
+            const int nl = (int)sh.ltotal;
+            for (int i = tid; i < nl; i += THQ_BLOCK) hist_key(true, sh.lall[i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) hist_key(have[j], k[j]);
         }
         if (coarse) {
 #pragma unroll
@@ -695,10 +816,12 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
         }
         __syncthreads();
         THQ_STAMP();   // histograms built
-        ok = coarse ? thq_exchange<2, true>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
-             : spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
-                    : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
-        ++tag; ++xstep; ++ptag;
+        if (!listed) {                                    // (a complete list: the local histogram IS the total)
+            ok = coarse ? thq_exchange<2, true>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
+                 : spec ? thq_exchange<2>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag)
+                        : thq_exchange<1>(sh, bufA, bufB, tag, xstep, G, hdr, spin_ticks, dbg, dbgi, pt, ptag);
+            ++tag; ++xstep; ++ptag;
+        }
         if (!ok) break;
         if (level == 0) {
             // out of [0, 1]: the generic form (workgroup 0, below) takes over
@@ -833,6 +956,8 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
     int rc = RLVI_E_LIMIT;
     bool launched = false;
     const int use_state = tune_get("RLVI_THR_WARM", 1);      // 0: never use the last call's key as a guess
+    // key-list finish once at most this many keys PER WORKGROUP (on average) are left inside the prefix; 0: never
+    const int list_per_wg = tune_get("RLVI_THR_LIST", 4);
 #define RLVI_THQ(E_, G_)                                                                         \
     do {                                                                                         \
         auto kern = threshold_radix_kernel<E_, TRUNC>;                                           \
@@ -840,7 +965,8 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
         if (!launched && (g_ == 1 || coop_cap(kern, THQ_BLOCK) >= g_) &&                           \
             (N + g_ - 1) / g_ <= (int64_t)(E_) * THQ_BLOCK) {                                      \
             rc = launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask,     \
-                        kept, ws, dbg, use_state, Nall, pt);                                     \
+                        kept, ws, dbg, use_state, Nall, pt,                                        \
+                        list_per_wg * g_ < THQ_LIST_ALL ? list_per_wg * g_ : THQ_LIST_ALL);      \
             launched = true;                                                                     \
         }                                                                                        \
     } while (0)

@@ -319,14 +319,14 @@ def epoch_end(residuals, weights, overfit=False, threshold=0, batches=0, tol=1e-
     return (thr.reshape(()) if overfit else threshold), (out if batches > 0 else None)
 
 
-def fn_threshold(weights, alpha=0.05):
+def fn_threshold(weights, alpha=0.05, ws=None):
     """false_negative_criterion (train_rlvi.py:41-49) -> 0-dim fp32 device tensor."""
     L = _lib.load()
     _require_gpu(weights)
     w = weights if (weights.dtype == torch.float32 and weights.is_contiguous()) \
         else weights.float().contiguous()
     thr = torch.empty(1, dtype=torch.float32, device=w.device)
-    ws = workspace(w.device, w.shape[0], 0)
+    ws = ws or workspace(w.device, w.shape[0], 0)
     _lib.check(L.rlvi_fn_threshold_f32(_ptr(w), w.shape[0], float(alpha), _ptr(thr), ws.ptr,
                                        _stream_ptr()), "rlvi_fn_threshold_f32")
     return thr.reshape(())

@@ -528,6 +528,51 @@ def test_threshold_randomised_ties_and_ranges(gpu, oracle):
     assert dev_status(ops, dev) == 0
 
 
+@pytest.mark.parametrize("N", [5000, 16385, 65536, 75750, 300000])
+def test_threshold_key_list_finish_and_its_fallbacks(N, gpu, oracle):
+    """threshold.hip finishes the descent on a list of the keys left inside the prefix (every workgroup
+    publishes at most 16 of its own, everybody reads everybody's) once few are left; more than 16 in one
+    workgroup and the histograms go on.  Vectors that take the list (random order), that overflow one
+    workgroup's 16 slots (sorted: the keys inside a prefix sit next to each other), that sit exactly at the cap
+    (16 and 17 equal-prefix keys in one workgroup's slice), heavy ties and plateaus -- cold and warm, with the
+    list off (RLVI_THR_LIST=0), at its default and far beyond it: the oracle's threshold, the truncated vector
+    and the mask bit for bit every time."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(N + 5)
+    base = rng.random(N).astype(np.float32)
+    cases = {"random": base, "ascending": np.sort(base), "descending": np.sort(base)[::-1].copy(),
+             "peaked": np.clip(1.0 - rng.random(N) ** 6, 0, 1).astype(np.float32),
+             "quantised": (rng.integers(0, 1000, N) / 999.0).astype(np.float32)}
+    for cap_fill in (16, 17):
+        # `cap_fill` keys that share their top 16 bits with the threshold's neighbourhood, next to each other
+        w = base.copy()
+        t0 = np.float32(oracle.false_negative_criterion(w))
+        lo = np.frombuffer(np.float32(t0).tobytes(), np.uint32)[0] & np.uint32(0xFFFF0000)
+        keys = (lo + rng.integers(0, 1 << 16, cap_fill).astype(np.uint32)).astype(np.uint32)
+        w[100:100 + cap_fill] = np.minimum(keys.view(np.float32), np.float32(1.0))
+        cases[f"cap{cap_fill}"] = w
+    try:
+        for name, w in cases.items():
+            thr_ref = oracle.false_negative_criterion(w)
+            w2 = w.copy()
+            m_ref = oracle.truncate(w2, thr_ref)
+            for lst in (4, 0, 16):
+                _lib.check(L.rlvi_tune_set(b"RLVI_THR_LIST", lst), "tune")
+                ws = ops.Workspace(dev, N, 0)                      # (no guess from another vector)
+                for rep in range(2):                               # cold, then warm from the same vector
+                    wt = torch.from_numpy(w.copy()).to(dev)
+                    assert float(ops.fn_threshold(wt, ws=ws)) == float(thr_ref), (name, lst, rep)
+                    thr2, mask, kept = ops.threshold_truncate(wt, 0.0, want_mask=True, ws=ws)
+                    assert float(thr2) == float(thr_ref), (name, lst, rep)
+                    assert np.array_equal(wt.cpu().numpy(), w2), (name, lst, rep)
+                    assert np.array_equal(mask.cpu().numpy(), m_ref) and int(kept) == int(m_ref.sum()), (name, lst)
+                assert ws.status() == 0
+    finally:
+        _lib.check(L.rlvi_tune_set(b"RLVI_THR_LIST", 4), "tune")
+
+
 @pytest.mark.parametrize("N", [6000, 24576, 70001, 131072])
 def test_estep_random_walk_of_inputs_on_one_workspace(N, gpu, oracle):
     """A long random sequence of very different loss vectors on ONE workspace: every call starts

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 from rlvi_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="mstep", choices=["mstep", "mstep_warm", "mstep_out", "estep", "thr", "fused", "mstep_fwd", "step"])
+ap.add_argument("--what", default="mstep", choices=["mstep", "mstep_warm", "mstep_out", "estep", "thr", "thr_fn", "fused", "mstep_fwd", "step"])
 ap.add_argument("--rows", type=int, default=65536)
 ap.add_argument("--classes", type=int, default=100)
 ap.add_argument("--n", type=int, default=0, help="E-step / threshold vector length (default rows)")
@@ -32,7 +32,7 @@ if a.dtype == "bf16":
 if N != B:
     from rlvi_amd import synth
     residuals_n = torch.from_numpy(synth.residual_vector("bimodal", N, 1)).to(dev)
-    weights_n = torch.rand(N, device=dev) if a.what == "thr" else torch.ones(N, device=dev)
+    weights_n = torch.rand(N, device=dev) if a.what in ("thr", "thr_fn") else torch.ones(N, device=dev)
 out = torch.empty(4, device=dev)
 iters = torch.zeros(1, dtype=torch.int32, device=dev)
 side = torch.cuda.Stream()
@@ -69,6 +69,11 @@ with torch.cuda.stream(side):
             L = _lib.load()
             _lib.check(L.rlvi_threshold_truncate_f32(ops._ptr(weights), weights.shape[0], 0.05, ops._ptr(thr),
                                                      None, None, ws.ptr, ops._stream_ptr()), "thr")
+        elif a.what == "thr_fn":           # the criterion alone: the vector is left as it is (no zeros from a truncation)
+            from rlvi_amd import _lib
+            L = _lib.load()
+            _lib.check(L.rlvi_fn_threshold_f32(ops._ptr(weights), weights.shape[0], 0.05, ops._ptr(thr),
+                                               ws.ptr, ops._stream_ptr()), "thr")
         elif a.what == "fused":
             ops.fused_em(logits[r], labels, pi, ws=ws, out=out, grad=grads[r], rows=rows, iters=iters)
     from rlvi_amd import _lib as _L
@@ -118,7 +123,7 @@ with torch.cuda.stream(side):
         sys.exit(0)
     best = time_leg()
     extra = describe(best)
-    if a.what == "thr" and any(t.startswith("RLVI_THR_DEBUG") for t in a.tune):
+    if a.what in ("thr", "thr_fn") and any(t.startswith("RLVI_THR_DEBUG") for t in a.tune):
         import numpy as np
         off = ops.debug_scratch_offset() + 256
         raw = ws.buf[off:off + 64 * 8].cpu().numpy().view(np.uint64)
