@@ -623,10 +623,20 @@ def main():
                        "rlvi_threshold_truncate_f32")
         extra["threshold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
         extra["threshold_n"] = N
+        # the criterion alone (false_negative_criterion, :41-49) on the E-step's pi as it is: the truncating call
+        # above re-runs on its own output, whose thousands of exact zeros are not what an epoch end sees
+        w_pi = weights.clone()
+
+        def criterion_only(i, ws):
+            from rlvi_amd import _lib
+            _lib.check(_lib.load().rlvi_fn_threshold_f32(ops._ptr(w_pi), N, 0.05, ops._ptr(thr_buf), ws.ptr,
+                                                         ops._stream_ptr()), "rlvi_fn_threshold_f32")
+        extra["criterion_us"] = timed(criterion_only, K, W, use_graph) / K * 1e3
         # (the same vector every call: every guess from the previous call is right.  Without any guess:)
         from rlvi_amd import _lib as _lt
         _lt.check(_lt.load().rlvi_tune_set(b"RLVI_THR_WARM", 0), "tune")
         extra["threshold_cold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
+        extra["criterion_cold_us"] = timed(criterion_only, K, W, use_graph) / K * 1e3
         _lt.check(_lt.load().rlvi_tune_set(b"RLVI_THR_WARM", 1), "tune")
         # in-batch E+M (V2): NLL pass -> E-step on this batch -> weighted loss + gradient
         pi_b = torch.ones(B, dtype=torch.float32, device=dev)
