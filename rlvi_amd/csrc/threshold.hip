@@ -269,9 +269,10 @@ struct ThqShared {
     unsigned long long wsum[2 * THQ_NW];   // cross-wave scratch of the reductions
     unsigned long long wcnt[2 * THQ_NW];
     uint32_t wmin[2 * THQ_NW];
-    uint32_t wtrue[THQ_NW];
-    unsigned long long r_sum;          // results of a scan
-    uint32_t r_min, r_b1;
+    struct Scan {                      // results of a scan (one slot per histogram: descend(0) and descend(1)
+        unsigned long long sum;        //  follow each other without a barrier in between)
+        uint32_t beta, b1, cab, mab, g0, below;
+    } r[2];
     int dead;
     uint32_t lcount, lover, ltotal;    // key-list finish: this workgroup's keys inside the prefix / somebody's overflow / all keys
     uint32_t lkeys[THQ_LIST_CAP];
@@ -674,41 +675,37 @@ __global__ __launch_bounds__(THQ_BLOCK) void threshold_radix_kernel(
             }
             const int b1w = THR_BINS - ntrue;                     // first bin whose suffix fits (256: none)
             if (lane == (b1w >> 2) || (b1w == THR_BINS && lane == 0))
-                sh.r_sum = b1w == THR_BINS ? 0ull : t4[b1w & 3];
-            if (lane == 0) { sh.r_b1 = (uint32_t)b1w; sh.r_min = __float_as_uint(beta); }
-        }
-        __syncthreads();
-        const int b1 = (int)sh.r_b1;
-        if (first) beta = __uint_as_float(sh.r_min);
-        // count / smallest key of the bins >= b1 (masked block reductions), first: the global minimum
-        {
-            const bool up = tid >= b1;
-            const unsigned long long cw = wave_sum_u32(up ? H.cnt[tid] : 0u);
-            const uint32_t mw = wave_min_key(up ? H.mn[tid] : 0xFFFFFFFFu);
-            const uint32_t gw = first ? wave_min_key(H.mn[tid]) : 0u;
-            if (lane == 0) { sh.wcnt[wave] = cw; sh.wmin[wave] = mw; sh.wtrue[wave] = gw; }
-        }
-        __syncthreads();
-        {
-            unsigned long long cab = 0ull;
-            uint32_t mab = 0xFFFFFFFFu, g0 = 0xFFFFFFFFu;
+                sh.r[hf].sum = b1w == THR_BINS ? 0ull : t4[b1w & 3];
+            // count / smallest key of the bins >= b1, first: the global minimum -- on this wave's own four bins
+            // per lane (round 2: a masked block reduction by all waves, two more barriers per digit)
+            uint32_t c4 = 0u, m4 = 0xFFFFFFFFu, g4 = 0xFFFFFFFFu;
 #pragma unroll
-            for (int wv = 0; wv < THQ_NW; ++wv) {
-                cab += sh.wcnt[wv];
-                mab = sh.wmin[wv] < mab ? sh.wmin[wv] : mab;
-                g0 = sh.wtrue[wv] < g0 ? sh.wtrue[wv] : g0;
+            for (int q = 0; q < 4; ++q) {
+                const int bin = 4 * lane + q;
+                const uint32_t cq = H.cnt[bin], mq = H.mn[bin];
+                if (bin >= b1w) { c4 += cq; m4 = mq < m4 ? mq : m4; }
+                g4 = mq < g4 ? mq : g4;
             }
-            if (first) gmin = g0;
-            if (b1 > 0) {
-                S_base += sh.r_sum;
-                cnt_base += cab;
-                above = mab < above ? mab : above;
-                // (coarse first digit: bin 1 stands for the guessed top byte)
-                prefix = (prefix << 8) | (uint32_t)(digit_of_bin1 >= 0 ? digit_of_bin1 : b1 - 1);
-                below_cnt = H.cnt[b1 - 1];
+            const uint32_t cab = wave_sum_u32(c4), mab = wave_min_key(m4);
+            const uint32_t g0 = first ? wave_min_key(g4) : 0u;
+            if (lane == 0) {
+                sh.r[hf].b1 = (uint32_t)b1w; sh.r[hf].beta = __float_as_uint(beta);
+                sh.r[hf].cab = cab; sh.r[hf].mab = mab; sh.r[hf].g0 = g0;
+                sh.r[hf].below = b1w > 0 ? H.cnt[b1w - 1] : 0u;
             }
         }
-        __syncthreads();                                  // r_*, w* are rewritten by the next scan
+        __syncthreads();
+        const int b1 = (int)sh.r[hf].b1;
+        if (first) { beta = __uint_as_float(sh.r[hf].beta); gmin = sh.r[hf].g0; }
+        if (b1 > 0) {
+            S_base += sh.r[hf].sum;
+            cnt_base += (unsigned long long)sh.r[hf].cab;
+            above = sh.r[hf].mab < above ? sh.r[hf].mab : above;
+            // (coarse first digit: bin 1 stands for the guessed top byte)
+            prefix = (prefix << 8) | (uint32_t)(digit_of_bin1 >= 0 ? digit_of_bin1 : b1 - 1);
+            below_cnt = sh.r[hf].below;
+        }
+        // (no barrier behind: the next scan of THIS slot comes after the barriers of a histogram pass)
         return b1;
     };
 
