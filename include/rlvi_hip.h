@@ -99,7 +99,9 @@ int rlvi_workspace_clear_status(void *ws, void *stream);
  * {loss_b, top-1 % of the batch, sum pi*l, hits} to its own record in the workspace (no atomics),
  * so a whole epoch of mini-batches costs one launch each, and rlvi_epoch_end_f32 (or
  * rlvi_mstep_reduce_f32) reduces and clears the records.  A call WITH `out` overwrites and then
- * clears the records it used, so do not interleave it with an accumulate sequence.
+ * clears the records it used, so do not interleave it with an accumulate sequence; it is a second
+ * (one-workgroup) launch behind the first: +2.6 us in the stream at 65 536 x 100, +1.8 us at
+ * 4096 x 10 -- a training loop that needs the batch scalars only at the epoch end wants ACCUMULATE.
  */
 int rlvi_mstep_fwd_bwd_f32(const float *logits, int64_t ld, const int64_t *labels,
                            const int64_t *idx, const float *weights, float *residuals,
