@@ -47,6 +47,97 @@ __device__ __forceinline__ float fe_grad(float e, float inv_s, bool label, float
     return label ? fmaf(-inv_scale, pw, p) : p;
 }
 
+// The batch's four scalars: one self-tagged record per workgroup (sc1 stores, one granule per lane),
+// workgroup 0 gathers the G records and adds them up in a fixed order.  (No release fence anywhere: a fence
+// would wait for this CU's share of the gradient stores to drain.)  All NW waves of the workgroup call;
+// acc / hits: this thread's share of sum pi*l and of the top-1 hits (a row counted by one thread).
+template <int NW>
+__device__ __forceinline__ void fe_batch_scalars(float acc, float hits, const TbSolved &sol, int64_t B,
+                                                 float inv_scale, float *__restrict__ out, void *ws, int b, int G) {
+    static_assert(NW * WAVE >= TB_G, "workgroup 0 reads one record per thread");
+    __shared__ double red[2 * NW];
+    __shared__ double fin[NW][PART_STRIDE];
+    __shared__ int fin_dead;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+    const double a = wave_sum((double)acc);
+    const double h = wave_sum((double)hits);
+    if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = h; }
+    __syncthreads();
+    const double inv_rows100 = 100.0 / (double)B;
+    double ta = 0.0, th = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { ta += red[2 * w]; th += red[2 * w + 1]; }
+    const double rec[PART_STRIDE] = {ta * (double)inv_scale, th * inv_rows100, ta, th};
+    if (out == nullptr) {
+        // accumulate for rlvi_epoch_end_f32, as rlvi_mstep_fwd_bwd_f32 without `out` does
+        if (tid == 0) {
+            double *p = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF) + (size_t)PART_STRIDE * b;
+#pragma unroll
+            for (int c = 0; c < PART_STRIDE; ++c) p[c] += rec[c];
+        }
+        return;
+    }
+    if (sol.dead) return;                 // (RLVI_ST_TIMEOUT is up: the host raises, `out` stays)
+    gu64 *frec = (gu64 *)(reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_FEREC_OFF));
+    const uint32_t ftag = sol.tag_free;
+    if (tid < 8) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(
+            (tid >> 1) == 0 ? rec[0] : (tid >> 1) == 1 ? rec[1] : (tid >> 1) == 2 ? rec[2] : rec[3]);
+        const uint32_t half = (tid & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        __hip_atomic_store(frec + (size_t)b * 8 + tid, ((unsigned long long)ftag << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (b != 0) return;
+    if (tid == 0) fin_dead = 0;
+    __syncthreads();
+    double t[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
+    if (wave < (G + WAVE - 1) / WAVE) {
+        const bool mine = tid < G;
+        const unsigned long long pa = (unsigned long long)(uintptr_t)(frec + (size_t)(mine ? tid : 0) * 8);
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long spin_ticks = spin_bound(hdr);
+        fe_vu4 r0, r1, r2, r3;
+        bool timeout = false;
+        for (unsigned spin = 0;; ++spin) {
+            asm volatile(
+                "global_load_dwordx4 %0, %4, off sc1\n\t"
+                "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                : "v"(pa)
+                : "memory");
+            const bool ok = !mine || (r0.y == ftag && r0.w == ftag && r1.y == ftag && r1.w == ftag &&
+                                      r2.y == ftag && r2.w == ftag && r3.y == ftag && r3.w == ftag);
+            if (__all(ok)) break;
+            if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
+        }
+        if (timeout) {
+            if (lane == 0) { atomicOr(&hdr->status, RLVI_ST_TIMEOUT); fin_dead = 1; }
+        } else if (mine) {
+            t[0] = __longlong_as_double((long long)(((unsigned long long)r0.z << 32) | r0.x));
+            t[1] = __longlong_as_double((long long)(((unsigned long long)r1.z << 32) | r1.x));
+            t[2] = __longlong_as_double((long long)(((unsigned long long)r2.z << 32) | r2.x));
+            t[3] = __longlong_as_double((long long)(((unsigned long long)r3.z << 32) | r3.x));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PART_STRIDE; ++c) {
+        t[c] = wave_sum(t[c]);
+        if (lane == 0) fin[wave][c] = t[c];
+    }
+    __syncthreads();
+    if (tid == 0 && fin_dead == 0) {
+        double r[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int c = 0; c < PART_STRIDE; ++c) r[c] += fin[w][c];
+        out[0] = (float)r[0]; out[1] = (float)r[1]; out[2] = (float)r[2]; out[3] = (float)r[3];
+    }
+}
+
 template <int KMAX, bool EXACT>
 __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     const float *__restrict__ logits, const int64_t *__restrict__ labels, float *__restrict__ loss_rows,
@@ -60,7 +151,6 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     __shared__ TbShared<FE_EB / WAVE, tb_stage(1, FE_EB)> sh;
     __shared__ float nll[FE_ROWS];
     __shared__ FeRow rowinfo[FE_WAVES][FE_TPW][FE_R];
-    __shared__ double red[2 * FE_WAVES];
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -268,89 +358,89 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
     }
 
     FE_STAMP(5);   // gradient stores issued
-    // ---- the batch's four scalars: one self-tagged record per workgroup (sc1 stores, one granule per
-    // lane), workgroup 0 gathers the G records and adds them up in a fixed order.  (No release fence
-    // anywhere: a fence would wait for this CU's share of the gradient stores to drain.)
-    const double a = wave_sum((double)(g == 0 ? acc : 0.0f));
-    const double h = wave_sum((double)(g == 0 ? hits : 0.0f));
-    if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = h; }
-    __syncthreads();
-    const double inv_rows100 = 100.0 / (double)B;
-    double ta = 0.0, th = 0.0;
-#pragma unroll
-    for (int w = 0; w < FE_WAVES; ++w) { ta += red[2 * w]; th += red[2 * w + 1]; }
-    const double rec[PART_STRIDE] = {ta * (double)inv_scale, th * inv_rows100, ta, th};
-    if (out == nullptr) {
-        // accumulate for rlvi_epoch_end_f32, as rlvi_mstep_fwd_bwd_f32 without `out` does
-        if (tid == 0) {
-            double *p = reinterpret_cast<double *>(static_cast<char *>(ws) + WS_PART_OFF) + (size_t)PART_STRIDE * b;
-#pragma unroll
-            for (int c = 0; c < PART_STRIDE; ++c) p[c] += rec[c];
-        }
-        return;
-    }
-    if (sol.dead) return;                 // (RLVI_ST_TIMEOUT is up: the host raises, `out` stays)
-    gu64 *frec = (gu64 *)(reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_FEREC_OFF));
-    const uint32_t ftag = sol.tag_free;
-    if (tid < 8) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(
-            (tid >> 1) == 0 ? rec[0] : (tid >> 1) == 1 ? rec[1] : (tid >> 1) == 2 ? rec[2] : rec[3]);
-        const uint32_t half = (tid & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-        __hip_atomic_store(frec + (size_t)b * 8 + tid, ((unsigned long long)ftag << 32) | half,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    FE_STAMP(6);   // record stored
-    if (b != 0) return;
-    __shared__ double fin[FE_WAVES][PART_STRIDE];
-    __shared__ int fin_dead;
-    if (tid == 0) fin_dead = 0;
-    __syncthreads();
-    double t[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
-    if (wave < (G + WAVE - 1) / WAVE) {
-        const bool mine = tid < G;
-        const unsigned long long pa = (unsigned long long)(uintptr_t)(frec + (size_t)(mine ? tid : 0) * 8);
-        const unsigned long long t0 = wall_clock64();
-        const unsigned long long spin_ticks = spin_bound(hdr);
-        fe_vu4 r0, r1, r2, r3;
-        bool timeout = false;
-        for (unsigned spin = 0;; ++spin) {
-            asm volatile(
-                "global_load_dwordx4 %0, %4, off sc1\n\t"
-                "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
-                "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                : "v"(pa)
-                : "memory");
-            const bool ok = !mine || (r0.y == ftag && r0.w == ftag && r1.y == ftag && r1.w == ftag &&
-                                      r2.y == ftag && r2.w == ftag && r3.y == ftag && r3.w == ftag);
-            if (__all(ok)) break;
-            if ((spin & 63u) == 63u && wall_clock64() - t0 > spin_ticks) { timeout = true; break; }
-        }
-        if (timeout) {
-            if (lane == 0) { atomicOr(&hdr->status, RLVI_ST_TIMEOUT); fin_dead = 1; }
-        } else if (mine) {
-            t[0] = __longlong_as_double((long long)(((unsigned long long)r0.z << 32) | r0.x));
-            t[1] = __longlong_as_double((long long)(((unsigned long long)r1.z << 32) | r1.x));
-            t[2] = __longlong_as_double((long long)(((unsigned long long)r2.z << 32) | r2.x));
-            t[3] = __longlong_as_double((long long)(((unsigned long long)r3.z << 32) | r3.x));
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < PART_STRIDE; ++c) {
-        t[c] = wave_sum(t[c]);
-        if (lane == 0) fin[wave][c] = t[c];
-    }
-    __syncthreads();
-    if (tid == 0 && fin_dead == 0) {
-        double r[PART_STRIDE] = {0.0, 0.0, 0.0, 0.0};
-        for (int w = 0; w < FE_WAVES; ++w)
-#pragma unroll
-            for (int c = 0; c < PART_STRIDE; ++c) r[c] += fin[w][c];
-        out[0] = (float)r[0]; out[1] = (float)r[1]; out[2] = (float)r[2]; out[3] = (float)r[3];
-    }
+    fe_batch_scalars<FE_WAVES>(g == 0 ? acc : 0.0f, g == 0 ? hits : 0.0f, sol, B, inv_scale, out, ws, b, G);
     FE_STAMP(7);   // out written
+}
+
+// ---------------------------------------------------------------------------------------
+// Short rows (C <= 16: the ten classes of MNIST / CIFAR-10, SURVEY cfg3 / cfg4): the same one launch with a ROW
+// PER THREAD.  A row is at most 16 registers, so nothing goes through LDS: a thread takes its row's max /
+// sum exp / NLL / top-1, the row's NLL IS the thread's sample of the trajectory solve (the grid and slices of
+// the stand-alone E-step: up to 256 workgroups of 256 threads, ceil(B / G) rows each), and the gradient comes
+// out of the registers the logits went into.  Column order inside a thread, so the NLL can differ in its last
+// bit from the M-step kernel's two-lanes-per-row sum; the composition stays the reference in the tests (pi,
+// loss rows and gradient to 1e-5, iteration count equal).  4096 <= B <= 65 536, fp32, dense rows.
+// ---------------------------------------------------------------------------------------
+constexpr int FR_CMAX = 16;
+constexpr int FR_THREADS = 256;
+
+__global__ __launch_bounds__(FR_THREADS) void fused_em_rows_kernel(
+    const float *__restrict__ logits, const int64_t *__restrict__ labels, float *__restrict__ loss_rows,
+    float *__restrict__ pi, int64_t B, int C, float inv_scale, float tol, int K,
+    float *__restrict__ grad, float *__restrict__ out, int32_t *__restrict__ out_iters, void *ws,
+    unsigned long long *__restrict__ dbg, int G, int verify) {
+    __shared__ TbShared<FR_THREADS / WAVE, tb_stage(1, FR_THREADS)> sh;
+    const int tid = threadIdx.x;
+    const int b = (int)blockIdx.x;
+    WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+    const int64_t L = (B + G - 1) / G;
+    const int64_t lo = (int64_t)b * L < B ? (int64_t)b * L : B;
+    const int64_t hi = lo + L < B ? lo + L : B;
+    const int64_t row = lo + tid;
+    const bool have = row < hi;
+    const TbWarm wm = tb_warm(ws, B, K);
+
+    // ---- 1  the row: max, sum exp, NLL, top-1 (train_rlvi.py:89, utils.py:58); exp(z - max) stays in z[]
+    float z[FR_CMAX];
+    float q0[1], l1[1], ev1[1];
+    q0[0] = have ? pi[row] : 0.0f;                                  // the caller's pi: D_0 of the E-step
+    int64_t y64 = have ? labels[row] : 0;
+#pragma unroll
+    for (int c = 0; c < FR_CMAX; ++c) z[c] = (have && c < C) ? logits[row * C + c] : -__builtin_inff();
+    bool okrow = have;
+    if (have && (y64 < 0 || y64 >= C)) { y64 = 0; okrow = false; }
+    if (have && !okrow) atomicOr(&hdr->status, RLVI_ST_RANGE);
+    const int y = (int)y64;
+    float m = z[0], zy = z[0];
+    int earlier = 0;
+#pragma unroll
+    for (int c = 1; c < FR_CMAX; ++c) m = __builtin_fmaxf(m, z[c]);
+#pragma unroll
+    for (int c = 0; c < FR_CMAX; ++c) {
+        zy = c == y ? z[c] : zy;
+        earlier += (c < y && z[c] == m) ? 1 : 0;                    // (torch.max: the FIRST column at the maximum)
+    }
+    float ssum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < FR_CMAX; ++c) {
+        z[c] = mexp(z[c] - m);                                      // (columns past C: exp(-inf) = 0)
+        ssum += z[c];
+    }
+    float l = __builtin_amdgcn_logf(ssum) * 0.69314718055994530942f - (zy - m);
+    const bool hit = okrow && zy == m && earlier == 0;
+    // a rejected row keeps the loss it had (the composition's forward pass skips it too)
+    if (have && !okrow) l = loss_rows[row];
+    l1[0] = have ? l : __builtin_inff();
+
+    // ---- 2  E-step on the workgroup's rows: one sample per thread, as estep_trajb_kernel<1, 256>
+    const TbSolved sol = trajb_solve<1, FR_THREADS>(sh, wm, l1, q0, ev1, true, b, G, B, tol, K, out_iters, nullptr,
+                                                    ws, dbg, nullptr, verify != 0);
+    const float pmax = tb_pmax(sol);
+
+    // ---- 3  pi, the loss row, the weighted gradient out of the registers
+    float acc = 0.0f;
+    if (!sol.dead && have) {
+        const float w = tb_weight(sol, pmax, ev1[0]);               // (:28, :30, :38)
+        const float pw = okrow ? w : 0.0f;                          // a rejected row: zero gradient
+        const float inv_s = (pw * inv_scale) * __builtin_amdgcn_rcpf(ssum);
+        loss_rows[row] = l - sol.gmin;                              // residuals.sub_(min) (:27)
+        pi[row] = w;
+#pragma unroll
+        for (int c = 0; c < FR_CMAX; ++c)
+            if (c < C) grad[row * C + c] = fe_grad(z[c], inv_s, c == y, pw, inv_scale);
+        acc = okrow ? l * pw : 0.0f;
+    }
+    fe_batch_scalars<FR_THREADS / WAVE>(acc, hit ? 1.0f : 0.0f, sol, B, inv_scale, out, ws, b, G);
 }
 
 // Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if the composition has to take it.
@@ -358,6 +448,21 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
                         int64_t B, int64_t C, float inv_scale, float tol, int maxiter, float *grad,
                         int64_t ldg, float *out, int32_t *out_iters, void *ws, hipStream_t st, int *rc) {
     if (tune_get("RLVI_FUSED_EM", 1) == 0) return 0;
+    if (grad != nullptr && ld == C && ldg == C && C <= FR_CMAX && B >= 4096 && maxiter >= 1 && maxiter <= TJ_MAXK) {
+        // short rows: a row per thread, the stand-alone E-step's grid (its admission rule too: every
+        // exchanging workgroup co-resident, node k reduced by workgroup k)
+        auto kern = fused_em_rows_kernel;
+        int G = coop_cap(kern, FR_THREADS);
+        if (G > TB_G) G = TB_G;
+        if (G >= TJ_MAXK && (B + G - 1) / G <= FR_THREADS) {
+            const int debug = tune_get("RLVI_TJ_DEBUG", 0);
+            unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+            *rc = launch(kern, dim3((unsigned)G), dim3(FR_THREADS), 0, st, logits, labels, loss_rows, pi, B, (int)C,
+                         inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G, tune_get("RLVI_TJ_VERIFY", 0));
+            return 1;
+        }
+        return 0;
+    }
     if (grad == nullptr || ld != C || ldg != C || (C & 3) || C < 32 || C > 128 || (B & 15)) return 0;
     if (((uintptr_t)logits & 15) || ((uintptr_t)grad & 15)) return 0;
     if (maxiter < 1 || maxiter > TJ_MAXK) return 0;
