@@ -656,6 +656,22 @@ def main():
         _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
         extra["fused_em_3launch_us"] = timed(fused_only, K, W, use_graph) / K * 1e3
         _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
+        # the same at the reference's own class count (cfg3 / cfg4: 4096 x 10): one launch, a row per thread
+        Bs, Cs = 4096, 10
+        g_s = torch.Generator(device="cpu").manual_seed(7)
+        z_s = (3.0 * torch.randn(Bs, Cs, generator=g_s)).to(dev)
+        y_s = torch.randint(0, Cs, (Bs,), generator=g_s).to(dev)
+        z_s[torch.arange(0, Bs, 2, device=dev), y_s[::2]] += 12.0
+        pi_s = torch.ones(Bs, dtype=torch.float32, device=dev)
+        rows_s = torch.empty(Bs, dtype=torch.float32, device=dev)
+        grad_s = torch.empty_like(z_s)
+
+        def fused_small(i, ws):
+            ops.fused_em(z_s, y_s, pi_s, ws=ws, out=out, grad=grad_s, rows=rows_s, iters=it_f)
+        extra["fused_em_4096x10_us"] = timed(fused_small, K, W, use_graph) / K * 1e3
+        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
+        extra["fused_em_4096x10_3launch_us"] = timed(fused_small, K, W, use_graph) / K * 1e3
+        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
         # the M-step at 4x the rows (3 rotating pairs = 630 MB): the same kernel with the fixed
         # launch / ramp-up share of a 10-us launch amortised -- separates steady-state bandwidth
         # from ramp-up by measurement
