@@ -140,8 +140,8 @@ with torch.cuda.stream(side):
         print("stamps (us since kernel start):", [round(float(x - st[0]) / 100.0, 2) for x in st][:16])
         if a.what == "fused":
             fs = ws.buf[off + 970 * 8:off + 978 * 8].cpu().numpy().view(np.uint64).astype(np.int64)
-            print("fused stamps [start, tiles landed, rows done, barrier, solved, grad issued, record, out] us:",
-                  [round(float(x - fs[0]) / 100.0, 2) for x in fs], " solve starts at", round(float(st[0] - fs[0]) / 100.0, 2))
+            print("fused stamps [start, tiles landed, rows done, barrier, solved, grad issued, -, out] us:",
+                  [round(float(x - fs[0]) / 100.0, 2) if x else None for x in fs], " solve starts at", round(float(st[0] - fs[0]) / 100.0, 2))
         print('finite mask %x scale' % int(raw[102]), np.array([raw[103] & 0xFFFFFFFF], np.uint32).view(np.float32), 'totals lanes0-7 (S,P,D):', raw[104:128].view(np.float64).reshape(8,3))
         print('round_ok', int(raw[128]), 'it', int(raw[129] >> 32), 'delta', np.array([raw[129] & 0xFFFFFFFF], np.uint32).view(np.float32))
         nn = raw[130:130+44]
