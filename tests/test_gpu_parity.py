@@ -573,6 +573,54 @@ def test_threshold_key_list_finish_and_its_fallbacks(N, gpu, oracle):
         _lib.check(L.rlvi_tune_set(b"RLVI_THR_LIST", 4), "tune")
 
 
+def test_threshold_randomised_distributions_on_one_workspace(gpu, oracle):
+    """120 random vectors through ONE workspace per size (so every call's first guesses come from an unrelated
+    vector): mixtures that put few, some or thousands of keys next to the threshold -- uniform, Beta-like peaks at
+    both ends, values quantised to 2^-8 ... 2^-20, blocks of equal values, sorted stretches (a workgroup's slice full
+    of neighbouring keys: the key list overflows and the histograms take over), exact zeros and ones.  Threshold,
+    truncated vector, mask and kept count bit for bit against the oracle; alpha and the previous threshold vary."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(77)
+    sizes = [4096, 20000, 65536, 100003]
+    wss = {n: ops.Workspace(dev, n, 0) for n in sizes}
+    for trial in range(120):
+        N = sizes[trial % len(sizes)]
+        kind = int(rng.integers(0, 6))
+        u = rng.random(N)
+        if kind == 0:
+            w = u
+        elif kind == 1:
+            w = 1.0 - u ** float(rng.choice([2, 4, 8]))                       # crowded towards 1
+        elif kind == 2:
+            w = u ** float(rng.choice([2, 4, 8]))                             # crowded towards 0
+        elif kind == 3:
+            q = float(2 ** int(rng.integers(8, 21)))
+            w = np.round(u * q) / q                                           # ties at every level of the descent
+        elif kind == 4:
+            w = np.sort(u)
+            lo = int(rng.integers(0, N // 2))
+            w[lo:lo + N // 4] = rng.permutation(w[lo:lo + N // 4])            # sorted, with a shuffled stretch
+        else:
+            w = np.where(u < 0.3, 0.0, np.where(u > 0.8, 1.0, rng.random(N)))
+            blk = int(rng.integers(1, 5000))
+            w[:blk] = w[blk]                                                  # a block of equal values
+        w = w.astype(np.float32)
+        alpha = float(rng.choice([0.05, 0.05, 0.01, 0.2]))
+        prev = float(rng.choice([0.0, 0.0, 0.5]))
+        thr_ref = oracle.false_negative_criterion(w, alpha=alpha)
+        expect = max(np.float32(prev), thr_ref)
+        w2 = w.copy()
+        m_ref = oracle.truncate(w2, expect)
+        wt = torch.from_numpy(w.copy()).to(dev)
+        assert float(ops.fn_threshold(wt, alpha=alpha, ws=wss[N])) == float(thr_ref), (trial, N, kind, alpha)
+        thr2, mask, kept = ops.threshold_truncate(wt, prev, alpha=alpha, want_mask=True, ws=wss[N])
+        assert float(thr2) == float(expect), (trial, N, kind, alpha)
+        assert np.array_equal(wt.cpu().numpy(), w2), (trial, N, kind)
+        assert np.array_equal(mask.cpu().numpy(), m_ref) and int(kept) == int(m_ref.sum()), (trial, N, kind)
+    for ws in wss.values():
+        assert ws.status() == 0
+
+
 @pytest.mark.parametrize("N", [6000, 24576, 70001, 131072])
 def test_estep_random_walk_of_inputs_on_one_workspace(N, gpu, oracle):
     """A long random sequence of very different loss vectors on ONE workspace: every call starts
