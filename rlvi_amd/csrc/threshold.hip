@@ -973,13 +973,15 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
     if (tune_get("RLVI_THR_RADIX", 1)) {
         const int force_g = tune_get("RLVI_THR_G", 0);
         if (N <= 1024 && !force_g && !sharded) RLVI_THQ(4, 1);
-        // the histogram costs about 1 us per key slot of a thread (LDS atomics), an exchange grows with
-        // the number of publishing workgroups: 64 workgroups up to one key per thread, 128 up to four,
-        // then 256 (measured at N = 65 536: 26.3 / 25.5 / 29.8 us for 64 / 128 / 256)
+        // the histogram costs about 1 us per key slot of a thread (LDS atomics), an exchange -- and the key
+        // list's hop -- grows with the number of publishing workgroups: 64 workgroups up to two keys per
+        // thread, 128 up to sixteen, then 256 (round 3, criterion alone: N = 32 768 16.5 / 17.3 us for 64 / 128;
+        // 65 536 18.5 / 18.1 / 20.4 for 64 / 128 / 256; 262 144 21.3 / 23.0 and 524 288 24.0 / 24.4 for 128 / 256;
+        // 1 048 576 29.0 / 26.7)
         for (int G = 64; G <= 256; G *= 2) {
             if (force_g && G != force_g) continue;
             const int64_t L = (N + G - 1) / G;
-            const int emax = force_g ? 32 : (G == 64 ? 1 : G == 128 ? 4 : 32);
+            const int emax = force_g ? 32 : (G == 64 ? 2 : G == 128 ? 16 : 32);
             if (L > (int64_t)THQ_BLOCK * emax) continue;
             if (L <= THQ_BLOCK * 1) RLVI_THQ(1, G);
             else if (L <= THQ_BLOCK * 2) RLVI_THQ(2, G);
