@@ -227,8 +227,9 @@ int rlvi_select_smallest_f32(const float *loss, int64_t n, int64_t k, float *mas
  * with the logit block resident in the chip's LDS between the two passes (fused_em.hip) for fp32
  * dense rows, 4 | C, 32 <= C <= 128, 16 | B, 16 129 <= B <= 65 536 on a 256-CU device (bit-identical
  * to the composition where the E-step slices coincide, a few ulp elsewhere), and with a row per thread
- * for fp32 dense rows of C <= 16 (the ten classes of MNIST / CIFAR-10), 4096 <= B <= 65 536 (pi, loss
- * rows and gradient within 1e-5 of the composition, same iteration count); three launches otherwise.
+ * for fp32 dense rows of C <= 16 (the ten classes of MNIST / CIFAR-10), 4096 <= B <= 65 536, or four
+ * lanes per row for 4 | C, 16 < C <= 128, 4096 <= B <= 16 384 (pi, loss rows and gradient within 1e-5
+ * of the composition, same iteration count); three launches otherwise.
  *   loss_rows [B] receives the min-shifted NLL, pi [B] the new posteriors (in/out).
  * ------------------------------------------------------------------------------------- */
 int rlvi_fused_em_f32(const float *logits, int64_t ld, const int64_t *labels, float *loss_rows,

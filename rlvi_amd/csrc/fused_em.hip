@@ -443,6 +443,104 @@ __global__ __launch_bounds__(FR_THREADS) void fused_em_rows_kernel(
     fe_batch_scalars<FR_THREADS / WAVE>(acc, hit ? 1.0f : 0.0f, sol, B, inv_scale, out, ws, b, G);
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide rows, small batches (4 | C, 16 < C <= 128, 4096 <= B <= 16 384: too few rows to give every CU the 256 the
+// LDS-resident kernel above wants, more columns than a thread's registers hold): four lanes per row as in the
+// M-step kernel, the row's vectors k * 4 + g in lane g's registers from the first read to the gradient's store,
+// 64 rows per workgroup of 256 threads.  Lane 0 of a row's group carries the row's NLL into the trajectory solve
+// as its sample (the other lanes hold pads, which drop out of every sum).
+// ---------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(FR_THREADS) void fused_em_rows4_kernel(
+    const float *__restrict__ logits, const int64_t *__restrict__ labels, float *__restrict__ loss_rows,
+    float *__restrict__ pi, int64_t B, int C, float inv_scale, float tol, int K,
+    float *__restrict__ grad, float *__restrict__ out, int32_t *__restrict__ out_iters, void *ws,
+    unsigned long long *__restrict__ dbg, int G, int verify) {
+    constexpr int V = 4, LG = 4, ROWS = FR_THREADS / LG;
+    __shared__ TbShared<FR_THREADS / WAVE, tb_stage(1, FR_THREADS)> sh;
+    const int tid = threadIdx.x;
+    const int g = tid & (LG - 1);
+    const int b = (int)blockIdx.x;
+    WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+    const int64_t row = (int64_t)b * ROWS + (tid >> 2);
+    const bool have = row < B;
+    const int nv = C / V;
+    const TbWarm wm = tb_warm(ws, B, K);
+
+    // ---- 1  the row: max, sum exp, NLL, top-1; exp(z - max) stays in v[][]
+    float q0[1], l1[1], ev1[1];
+    q0[0] = (have && g == 0) ? pi[row] : 0.0f;
+    int64_t y64 = have ? labels[row] : 0;
+    float v[KMAX][V];
+    bool live[KMAX];
+    const float *zrow = logits + (have ? row : 0) * C;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int vec = k * LG + g;
+        live[k] = vec < nv;
+        const float4 t = *reinterpret_cast<const float4 *>(zrow + (live[k] ? vec : 0) * V);
+        v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+    }
+    bool okrow = have;
+    if (have && (y64 < 0 || y64 >= C)) { y64 = 0; okrow = false; }
+    if (have && !okrow && g == 0) atomicOr(&hdr->status, RLVI_ST_RANGE);
+    const int y = (int)y64;
+    const float zy = zrow[y];
+    float m = v[0][0];                                               // (lane g's vector 0 exists: nv >= 4)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) m = live[k] ? __builtin_fmaxf(m, v[k][e]) : m;
+    m = group_allreduce<LG>(m, [](float a, float c) { return __builtin_fmaxf(a, c); });
+    int earlier = 0;
+    float ssum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int col = (k * LG + g) * V + e;
+            earlier += (live[k] && v[k][e] == m && col < y) ? 1 : 0;   // (torch.max: the FIRST column at the maximum)
+            const float ex = mexp(v[k][e] - m);
+            v[k][e] = ex;
+            ssum += live[k] ? ex : 0.0f;
+        }
+    ssum = group_sum<LG>(ssum);
+    earlier = group_allreduce<LG>(earlier, FAdd());
+    float l = __builtin_amdgcn_logf(ssum) * 0.69314718055994530942f - (zy - m);
+    const bool hit = okrow && zy == m && earlier == 0;
+    // a rejected row keeps the loss it had (the composition's forward pass skips it too)
+    if (have && !okrow) l = loss_rows[row];
+    l1[0] = (have && g == 0) ? l : __builtin_inff();
+
+    // ---- 2  E-step: the rows of this workgroup are its slice, one sample in every fourth thread
+    const TbSolved sol = trajb_solve<1, FR_THREADS>(sh, wm, l1, q0, ev1, true, b, G, B, tol, K, out_iters, nullptr,
+                                                    ws, dbg, nullptr, verify != 0);
+    const float pmax = tb_pmax(sol);
+
+    // ---- 3  pi, the loss row, the weighted gradient out of the registers
+    float acc = 0.0f;
+    if (!sol.dead && have) {
+        const float lv = l - sol.gmin;                               // residuals.sub_(min) (:27)
+        const float w = tb_weight(sol, pmax, expf(-lv));             // (:28, :30, :38)
+        const float pw = okrow ? w : 0.0f;                           // a rejected row: zero gradient
+        const float inv_s = (pw * inv_scale) * __builtin_amdgcn_rcpf(ssum);
+        if (g == 0) { loss_rows[row] = lv; pi[row] = w; acc = okrow ? l * pw : 0.0f; }
+        float *grow = grad + row * C;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (!live[k]) continue;
+            const int col = (k * LG + g) * V;
+            float4 o;
+            o.x = fe_grad(v[k][0], inv_s, col == y, pw, inv_scale);
+            o.y = fe_grad(v[k][1], inv_s, col + 1 == y, pw, inv_scale);
+            o.z = fe_grad(v[k][2], inv_s, col + 2 == y, pw, inv_scale);
+            o.w = fe_grad(v[k][3], inv_s, col + 3 == y, pw, inv_scale);
+            *reinterpret_cast<float4 *>(grow + col) = o;
+        }
+    }
+    fe_batch_scalars<FR_THREADS / WAVE>(acc, (hit && g == 0) ? 1.0f : 0.0f, sol, B, inv_scale, out, ws, b, G);
+}
+
 // Eligibility + launch.  Returns 1 if launched (rc in *rc), 0 if the composition has to take it.
 int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, float *loss_rows, float *pi,
                         int64_t B, int64_t C, float inv_scale, float tol, int maxiter, float *grad,
@@ -462,6 +560,22 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
             return 1;
         }
         return 0;
+    }
+    if (grad != nullptr && ld == C && ldg == C && !(C & 3) && C > FR_CMAX && C <= 128 && B >= 4096 &&
+        B <= (int64_t)TB_G * (FR_THREADS / 4) && maxiter >= 1 && maxiter <= TJ_MAXK &&
+        !(((uintptr_t)logits & 15) || ((uintptr_t)grad & 15))) {
+        // wide rows, too few of them for the LDS-resident kernel below: four lanes per row, 64 rows per workgroup
+        const int G = (int)((B + FR_THREADS / 4 - 1) / (FR_THREADS / 4));
+        const int debug = tune_get("RLVI_TJ_DEBUG", 0);
+        unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
+        const int verify = tune_get("RLVI_TJ_VERIFY", 0);
+        auto go = [&](auto kern) {
+            if (G < TJ_MAXK || coop_cap(kern, FR_THREADS) < G) return 0;     // all G workgroups must be resident
+            *rc = launch(kern, dim3((unsigned)G), dim3(FR_THREADS), 0, st, logits, labels, loss_rows, pi, B, (int)C,
+                         inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G, verify);
+            return 1;
+        };
+        return C <= 64 ? go(fused_em_rows4_kernel<4>) : go(fused_em_rows4_kernel<8>);
     }
     if (grad == nullptr || ld != C || ldg != C || (C & 3) || C < 32 || C > 128 || (B & 15)) return 0;
     if (((uintptr_t)logits & 15) || ((uintptr_t)grad & 15)) return 0;

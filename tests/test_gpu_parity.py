@@ -926,10 +926,12 @@ def test_fused_em_one_launch_equals_the_three_launch_composition(B, C, gpu, orac
 
 
 @pytest.mark.parametrize("B,C", [(4096, 10), (5003, 10), (45000, 10), (65536, 16), (20000, 7), (8192, 2),
-                                 (54000, 10)])
+                                 (54000, 10),
+                                 (4096, 100), (8191, 100), (16384, 64), (5000, 20), (12000, 128), (16384, 100)])
 def test_fused_em_short_rows_in_one_launch(B, C, gpu, oracle):
-    """C <= 16 (the ten classes of cfg3 / cfg4): the in-batch E+M as ONE launch with a row per thread
-    (fused_em.hip: fused_em_rows_kernel) against the three-launch composition and against the oracle -- ties at
+    """The in-batch E+M as ONE launch with the rows in registers (fused_em.hip) -- C <= 16 (the ten classes of
+    cfg3 / cfg4): a row per thread (fused_em_rows_kernel); 4 | C, 16 < C <= 128 at 4096 ... 16 384 rows: four lanes
+    per row (fused_em_rows4_kernel) -- against the three-launch composition and against the oracle: ties at
     the row maximum, a few labels out of range (status, zero gradient, the loss they had), twice through one
     workspace.  A thread adds its row's exponentials in column order, the M-step kernel two lanes' partial sums:
     the NLL may differ in its last bit, so pi / gradient / loss rows are held to the path's 1e-5 bar here and the
