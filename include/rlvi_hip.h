@@ -151,7 +151,7 @@ int rlvi_estep_deep_f32(float *residuals, float *weights, int64_t N, float tol, 
  *       answers before the first collective call.  The sharded solve uses the 256-thread geometry on
  *       every rank (shards may differ in length; the exchanged record layout may not).
  *   rlvi_estep_sharded_f32   a collective: every rank calls it the same number of times; returns
- *       RLVI_E_LIMIT when the shape is outside the trajectory kernel (n_local < 4096, ...).
+ *       RLVI_E_LIMIT when the shape is outside the trajectory kernel (n_local < 64, ...).
  *       out != NULL: this rank's M-step scalars of the epoch too (as rlvi_epoch_end_f32, x 1/batches).
  *       Waits on a peer are bounded by 100 x the workspace's spin bound (a peer may legitimately be
  *       late); a rank that gives up raises RLVI_ST_TIMEOUT.
@@ -227,8 +227,8 @@ int rlvi_select_smallest_f32(const float *loss, int64_t n, int64_t k, float *mas
  * with the logit block resident in the chip's LDS between the two passes (fused_em.hip) for fp32
  * dense rows, 4 | C, 32 <= C <= 128, 16 | B, 16 129 <= B <= 65 536 on a 256-CU device (bit-identical
  * to the composition where the E-step slices coincide, a few ulp elsewhere), and with a row per thread
- * for fp32 dense rows of C <= 16 (the ten classes of MNIST / CIFAR-10), 4096 <= B <= 65 536, or four
- * lanes per row for 4 | C, 16 < C <= 128, 4096 <= B <= 16 384 (pi, loss rows and gradient within 1e-5
+ * for fp32 dense rows of C <= 16 (the ten classes of MNIST / CIFAR-10), 64 <= B <= 65 536, or four
+ * lanes per row for 4 | C, 16 < C <= 128, 64 <= B <= 16 384 (pi, loss rows and gradient within 1e-5
  * of the composition, same iteration count); three launches otherwise.
  *   loss_rows [B] receives the min-shifted NLL, pi [B] the new posteriors (in/out).
  * ------------------------------------------------------------------------------------- */

@@ -1,5 +1,5 @@
-// Trajectory E-step (train_rlvi.py:14-38; N from 4096 to 2 097 152: the bench size, every dataset
-// of the reference, the weak-scaling bench up to 8 x 65 536).
+// Trajectory E-step (train_rlvi.py:14-38; N from 64 to 2 097 152: the bench size, every dataset
+// of the reference, the weak-scaling bench up to 8 x 65 536, and a mini-batch's worth of samples).
 //
 // Guessed nodes r'_k of the whole fixed-point trajectory (rlvi_traj.h holds the recurrence), per
 // round the totals S(r'_k), dS/dr, -d2S/dr2 / 2 and D(r'_k, r'_{k-1}) for all nodes, a corrected
@@ -102,7 +102,10 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
                            float *mstep_out, double mstep_scale, int *rc, int64_t n_all, int sharded,
                            int dry_run) {
     const int mode = tune_get("RLVI_ESTEP_TRAJB", 1);
-    const int64_t nmin = tune_get("RLVI_ESTEP_TRAJB_NMIN", 4096);
+    // (round 3: from 64 samples on -- the solve costs its ~10.5 us whatever N is, the iterative kernel 0.8-1.8 us
+    //  per iteration: N = 256 16.5 -> 12.0 us, 1024 20.6 -> 12.3, 3000 37.9 -> 12.4 with the copy kernel of the
+    //  timing loop; rounds 1-2 had started at 4096 because the slices of their node-per-workgroup form needed it)
+    const int64_t nmin = tune_get("RLVI_ESTEP_TRAJB_NMIN", 64);
     if (mode == 0 || maxiter < 1 || maxiter > TJ_MAXK || N < nmin) return 0;
     const int debug = tune_get("RLVI_TJ_DEBUG", 0);
     // 256 threads measured 2-3 us per call ahead up to N = 262 144, level at 524 288, 1 us behind

@@ -456,14 +456,15 @@ __global__ __launch_bounds__(FR_THREADS) void fused_em_rows4_kernel(
     float *__restrict__ pi, int64_t B, int C, float inv_scale, float tol, int K,
     float *__restrict__ grad, float *__restrict__ out, int32_t *__restrict__ out_iters, void *ws,
     unsigned long long *__restrict__ dbg, int G, int verify) {
-    constexpr int V = 4, LG = 4, ROWS = FR_THREADS / LG;
+    constexpr int V = 4, LG = 4;
     __shared__ TbShared<FR_THREADS / WAVE, tb_stage(1, FR_THREADS)> sh;
     const int tid = threadIdx.x;
     const int g = tid & (LG - 1);
     const int b = (int)blockIdx.x;
     WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
-    const int64_t row = (int64_t)b * ROWS + (tid >> 2);
-    const bool have = row < B;
+    const int64_t L = (B + G - 1) / G;                               // rows of a workgroup (<= ROWS: the launcher)
+    const int64_t row = (int64_t)b * L + (tid >> 2);
+    const bool have = (tid >> 2) < L && row < B;
     const int nv = C / V;
     const TbWarm wm = tb_warm(ws, B, K);
 
@@ -546,7 +547,7 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
                         int64_t B, int64_t C, float inv_scale, float tol, int maxiter, float *grad,
                         int64_t ldg, float *out, int32_t *out_iters, void *ws, hipStream_t st, int *rc) {
     if (tune_get("RLVI_FUSED_EM", 1) == 0) return 0;
-    if (grad != nullptr && ld == C && ldg == C && C <= FR_CMAX && B >= 4096 && maxiter >= 1 && maxiter <= TJ_MAXK) {
+    if (grad != nullptr && ld == C && ldg == C && C <= FR_CMAX && B >= 64 && maxiter >= 1 && maxiter <= TJ_MAXK) {
         // short rows: a row per thread, the stand-alone E-step's grid (its admission rule too: every
         // exchanging workgroup co-resident, node k reduced by workgroup k)
         auto kern = fused_em_rows_kernel;
@@ -561,16 +562,18 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
         }
         return 0;
     }
-    if (grad != nullptr && ld == C && ldg == C && !(C & 3) && C > FR_CMAX && C <= 128 && B >= 4096 &&
+    if (grad != nullptr && ld == C && ldg == C && !(C & 3) && C > FR_CMAX && C <= 128 && B >= 64 &&
         B <= (int64_t)TB_G * (FR_THREADS / 4) && maxiter >= 1 && maxiter <= TJ_MAXK &&
         !(((uintptr_t)logits & 15) || ((uintptr_t)grad & 15))) {
-        // wide rows, too few of them for the LDS-resident kernel below: four lanes per row, 64 rows per workgroup
-        const int G = (int)((B + FR_THREADS / 4 - 1) / (FR_THREADS / 4));
+        // wide rows, too few of them for the LDS-resident kernel below: four lanes per row, up to 64 rows per
+        // workgroup on as many workgroups as are co-resident (at most 256)
         const int debug = tune_get("RLVI_TJ_DEBUG", 0);
         unsigned long long *dbg = debug ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
         const int verify = tune_get("RLVI_TJ_VERIFY", 0);
         auto go = [&](auto kern) {
-            if (G < TJ_MAXK || coop_cap(kern, FR_THREADS) < G) return 0;     // all G workgroups must be resident
+            int G = coop_cap(kern, FR_THREADS);
+            if (G > TB_G) G = TB_G;
+            if (G < TJ_MAXK || (B + G - 1) / G > FR_THREADS / 4) return 0;   // node k is reduced by workgroup k; 64 rows each
             *rc = launch(kern, dim3((unsigned)G), dim3(FR_THREADS), 0, st, logits, labels, loss_rows, pi, B, (int)C,
                          inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G, verify);
             return 1;

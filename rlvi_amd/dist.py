@@ -121,7 +121,7 @@ def set_owner_sharding(owned, ws, peers, n_all=None, with_scalars=True):
         dist.all_gather_object(oks, bool(ok))
         if not all(oks):
             raise RlviError("owner sharding: the sharded E-step / threshold cannot launch on every rank "
-                            f"(shares {total}, launchable {oks}; 4096 .. 2097152 samples per rank, fewer at "
+                            f"(shares {total}, launchable {oks}; 1025 .. 2097152 samples per rank, fewer at "
                             "the upper end when several ranks share one GPU)")
     _OWNER = None if owned is None else (owned, ws, peers)
 

@@ -433,11 +433,12 @@ def test_threshold_vs_oracle_sizes(N, gpu, oracle):
     assert ops.workspace(dev).status() == 0
 
 
-@pytest.mark.parametrize("N", [1, 5, 1000, 4096, 4097, 8193, 12287, 12288, 24576, 50000, 65536, 75750, 200000,
+@pytest.mark.parametrize("N", [1, 5, 63, 64, 65, 100, 255, 256, 257, 1000, 2047, 3000, 4095, 4096, 4097, 8193,
+                               12287, 12288, 24576, 50000, 65536, 75750, 200000,
                                200001, 262144, 524288, 600000, 1000003, 1966080, 2097152, 2097153])
 def test_estep_vs_oracle_sizes(N, gpu, oracle):
-    """Iterative (N < 4096, N > 2 097 152), node-per-workgroup trajectory (4096..12 287) and
-    slice-per-workgroup trajectory (12 288..2 097 152) solvers.
+    """Iterative (N < 64, N > 2 097 152) and trajectory (64..2 097 152: from fewer samples than exchanging
+    workgroups -- most slices empty -- to 32 samples per thread) solvers.
 
     Determinism: from the same workspace state two runs are bit-identical (fixed reduction
     order -- this is also the race detector).  The trajectory solver warm-starts from the last
@@ -470,7 +471,7 @@ def test_estep_vs_oracle_sizes(N, gpu, oracle):
     assert outs[0][1].max() == np.float32(1.0)           # weights.div_(weights.max()) (:38)
 
 
-@pytest.mark.parametrize("N", [12000, 30000, 300000])
+@pytest.mark.parametrize("N", [64, 200, 1000, 3500, 12000, 30000, 300000])
 def test_estep_trajectory_cold_warm_and_poor_guess(N, gpu, oracle):
     """The trajectory solver must not depend on the quality of its starting guess: cold start,
     warm start from the same data, and warm start from a very different vector of the same
@@ -621,7 +622,7 @@ def test_threshold_randomised_distributions_on_one_workspace(gpu, oracle):
         assert ws.status() == 0
 
 
-@pytest.mark.parametrize("N", [6000, 24576, 70001, 131072])
+@pytest.mark.parametrize("N", [70, 300, 1500, 6000, 24576, 70001, 131072])
 def test_estep_random_walk_of_inputs_on_one_workspace(N, gpu, oracle):
     """A long random sequence of very different loss vectors on ONE workspace: every call starts
     from the previous call's (now arbitrary) trajectory -- scaled, shifted, mixed and degenerate
@@ -926,11 +927,12 @@ def test_fused_em_one_launch_equals_the_three_launch_composition(B, C, gpu, orac
 
 
 @pytest.mark.parametrize("B,C", [(4096, 10), (5003, 10), (45000, 10), (65536, 16), (20000, 7), (8192, 2),
-                                 (54000, 10),
-                                 (4096, 100), (8191, 100), (16384, 64), (5000, 20), (12000, 128), (16384, 100)])
+                                 (54000, 10), (64, 10), (100, 10), (257, 10), (1000, 10),
+                                 (4096, 100), (8191, 100), (16384, 64), (5000, 20), (12000, 128), (16384, 100),
+                                 (70, 100), (300, 100), (1000, 128), (2048, 100)])
 def test_fused_em_short_rows_in_one_launch(B, C, gpu, oracle):
     """The in-batch E+M as ONE launch with the rows in registers (fused_em.hip) -- C <= 16 (the ten classes of
-    cfg3 / cfg4): a row per thread (fused_em_rows_kernel); 4 | C, 16 < C <= 128 at 4096 ... 16 384 rows: four lanes
+    cfg3 / cfg4): a row per thread (fused_em_rows_kernel); 4 | C, 16 < C <= 128 at 64 ... 16 384 rows: four lanes
     per row (fused_em_rows4_kernel) -- against the three-launch composition and against the oracle: ties at
     the row maximum, a few labels out of range (status, zero gradient, the loss they had), twice through one
     workspace.  A thread adds its row's exponentials in column order, the M-step kernel two lanes' partial sums:
