@@ -18,8 +18,10 @@
 // Same arithmetic, operation for operation, as the three-launch composition in aux.hip
 // (rlvi_mstep_fwd_bwd_f32 -> rlvi_estep_deep_f32 -> rlvi_mstep_fwd_bwd_f32): pi, the loss rows and
 // the gradient are bit-identical to it (tests/test_gpu_parity.py).  Eligibility: fp32, dense rows,
-// 4 | C, 32 <= C <= 128 (four lanes per row there too), 16 | B, 64 <= ceil(B/256) <= the co-resident workgroups of this device; everything
-// else takes the composition.
+// 4 | C, 32 <= C <= 128 (four lanes per row there too), 16 | B, 64 <= ceil(B/256) <= the co-resident workgroups of this device.
+// Below that, the rows stay in REGISTERS (further down): C <= 16 a row per thread (64 <= B <= 65 536), wider rows
+// four lanes per row (4 | C, C <= 128, 64 <= B <= 16 384).  Everything else (bf16, rows that are no multiple of
+// four columns, strided rows) takes the composition.
 #include "rlvi_trajb.h"
 
 namespace rlvi {
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(FE_THREADS) void fused_em_kernel(
 // the stand-alone E-step: up to 256 workgroups of 256 threads, ceil(B / G) rows each), and the gradient comes
 // out of the registers the logits went into.  Column order inside a thread, so the NLL can differ in its last
 // bit from the M-step kernel's two-lanes-per-row sum; the composition stays the reference in the tests (pi,
-// loss rows and gradient to 1e-5, iteration count equal).  4096 <= B <= 65 536, fp32, dense rows.
+// loss rows and gradient to 1e-5, iteration count equal).  64 <= B <= 65 536, fp32, dense rows.
 // ---------------------------------------------------------------------------------------
 constexpr int FR_CMAX = 16;
 constexpr int FR_THREADS = 256;
@@ -444,10 +446,10 @@ __global__ __launch_bounds__(FR_THREADS) void fused_em_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Wide rows, small batches (4 | C, 16 < C <= 128, 4096 <= B <= 16 384: too few rows to give every CU the 256 the
+// Wide rows, small batches (4 | C, 16 < C <= 128, 64 <= B <= 16 384: too few rows to give every CU the 256 the
 // LDS-resident kernel above wants, more columns than a thread's registers hold): four lanes per row as in the
 // M-step kernel, the row's vectors k * 4 + g in lane g's registers from the first read to the gradient's store,
-// 64 rows per workgroup of 256 threads.  Lane 0 of a row's group carries the row's NLL into the trajectory solve
+// up to 64 rows per workgroup of 256 threads.  Lane 0 of a row's group carries the row's NLL into the trajectory solve
 // as its sample (the other lanes hold pads, which drop out of every sum).
 // ---------------------------------------------------------------------------------------
 template <int KMAX>
