@@ -18,9 +18,8 @@ from .standard import _dev
 
 def update_weights_rlvi(losses, tol=1e-3, maxiter=100):
     '''Optimize Bernoulli probabilities (reference main.py:45-58).'''
-    l = torch.from_numpy(np.ascontiguousarray(losses, dtype=np.float64)).to(_dev())
-    w, _ = ops.update_weights_f64(l, tol=tol, maxiter=maxiter, online=True)
-    return w.cpu().numpy()
+    from .standard import _roundtrip_f64
+    return _roundtrip_f64(losses, lambda l: ops.update_weights_f64(l, tol=tol, maxiter=maxiter, online=True)[0])
 
 
 def cross_entropy(log_proba, targets):
