@@ -39,7 +39,10 @@
 extern "C" {
 #endif
 
-#define RLVI_ABI_VERSION 2   /* 2: workspace layout of round 2 (peer table, sharded state), rlvi_device_pci_bus_id,
+#define RLVI_ABI_VERSION 3   /* 3: calls with `out` have records of their own (workspace layout), per-workspace options,
+                                 rlvi_tune_unset / _overrides, rlvi_linear_regression_f64, rlvi_sample_weight_online_f64,
+                                 rlvi_workspace_region / _reset_warm, rlvi_stream_copy
+                                 2: workspace layout of round 2 (peer table, sharded state), rlvi_device_pci_bus_id,
                                  rlvi_estep_sharded_check; set_peers zeroes the local inbox */
 
 #define RLVI_E_NULL   (-1) /* required pointer is NULL                 */
@@ -63,6 +66,11 @@ const char *rlvi_error_string(int code);
 /* Integer tuning / debug knob (same names as the RLVI_* environment variables, which it
  * overrides); takes effect from the next launch.  Not needed for normal operation. */
 int rlvi_tune_set(const char *name, int value);
+/* Forget a rlvi_tune_set value (environment variable / built-in default again); 1 if there was one, else 0. */
+int rlvi_tune_unset(const char *name);
+/* Names of the knobs that carry a rlvi_tune_set value now, comma-separated, into buf[len]; returns their number.
+ * The knobs are process-wide: a test harness asserts 0 after every test. */
+int rlvi_tune_overrides(char *buf, int len);
 /* Compute units of the current device as the launchers see them. */
 int rlvi_device_cus(void);
 /* PCI bus id ("0000:c1:00.0") of the current device into buf[len >= 16]: the identity of the physical GPU,
@@ -77,6 +85,21 @@ int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream);
 int rlvi_workspace_status(const void *ws, int32_t *status_host, void *stream);
 /* Reset the sticky status word to 0 (nothing else: warm-start state and records are kept). */
 int rlvi_workspace_clear_status(void *ws, void *stream);
+/* What the CALLER of this workspace tells the launchers (host side, per workspace, from the next launch on;
+ * rlvi_workspace_init forgets it):
+ *   "logits_from_hbm" 1: the [B, C] blocks of the M-step calls on this workspace stream from HBM (larger than the
+ *       Infinity Cache, or one of many blocks touched in rotation): a one-tile-per-wave launch then holds its
+ *       gradient stores for the read time of the block (mstep.hip); 0 (default): nothing is assumed;
+ *   "cold_start" 1: E-step and threshold take no guess from the previous call on this workspace (every call as the
+ *       reference's loop starts it, train_rlvi.py:29; the results never depend on the guesses, only the time does).
+ * RLVI_E_SHAPE for an unknown name. */
+int rlvi_workspace_set_option(void *ws, const char *name, int value);
+/* Forget the guesses earlier calls left for the next one (E-step trajectory and minimum, threshold key). */
+int rlvi_workspace_reset_warm(void *ws, void *stream);
+/* Byte offset (and size through *bytes) of a region of the workspace layout, for tools and tests: "records"
+ * (accumulate-mode M-step records), "records_out" (records of calls with `out`), "warm", "scratch"; (size_t)-1
+ * for an unknown name. */
+size_t rlvi_workspace_region(const char *name, size_t *bytes);
 
 /* ---------------------------------------------------------------------------------------
  * M-step over one mini-batch, forward + backward w.r.t. the logits, lagged pi.
@@ -98,10 +121,11 @@ int rlvi_workspace_clear_status(void *ws, void *stream);
  * out == NULL selects ACCUMULATE mode: nothing is finalised; every workgroup adds its partial sums
  * {loss_b, top-1 % of the batch, sum pi*l, hits} to its own record in the workspace (no atomics),
  * so a whole epoch of mini-batches costs one launch each, and rlvi_epoch_end_f32 (or
- * rlvi_mstep_reduce_f32) reduces and clears the records.  A call WITH `out` overwrites and then
- * clears the records it used, so do not interleave it with an accumulate sequence; it is a second
- * (one-workgroup) launch behind the first: +2.6 us in the stream at 65 536 x 100, +1.8 us at
- * 4096 x 10 -- a training loop that needs the batch scalars only at the epoch end wants ACCUMULATE.
+ * rlvi_mstep_reduce_f32) reduces and clears the records.  A call WITH `out` keeps its records apart
+ * (ABI 3) -- it may be interleaved with an accumulate sequence on the same workspace, e.g. an evaluation
+ * batch between two training batches -- and is a second (one-workgroup) launch behind the first: +2.6 us
+ * in the stream at 65 536 x 100, +1.8 us at 4096 x 10 -- a training loop that needs the batch scalars
+ * only at the epoch end wants ACCUMULATE.
  */
 int rlvi_mstep_fwd_bwd_f32(const float *logits, int64_t ld, const int64_t *labels,
                            const int64_t *idx, const float *weights, float *residuals,
@@ -267,6 +291,40 @@ int rlvi_linreg_losses_f64(const double *X, const double *y, const double *theta
                            double *sigma2_out, void *ws, void *stream);
 int rlvi_logistic_nll_f64(const double *X, const double *w, double b, int64_t n, int64_t d,
                           double *losses, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The whole estimator linear_regression(X, y, maxiter=100, tol=1e-3) of standard-learning/rlvi.py:68-89 as ONE
+ * launch (standard.hip): weights = 1, weighted least squares (:70-71), Gaussian NLL (:72-74), then up to `maxiter`
+ * times { update_weights(losses) with (estep_tol, estep_maxiter) = the reference's (1e-3, 100) (:77 -> :8-20),
+ * weighted least squares (:79-80), NLL (:81-83), stop when ||theta - prev|| / ||prev|| <= tol (:85-87) } -- the
+ * stop decision is taken on the device, the host waits once, for the result.  One persistent workgroup: the
+ * weighted Gram matrix and X.theta on the fp64 matrix cores, an L D L^T solve on one wave.
+ *   theta [d], weights [n] (the final pi), info int32[4] = { outer iterations, inner iterations of the last
+ *   E-step, inner iterations in all, fallback } -- all device pointers.
+ * n <= 4096 and d <= 31 (rlvi_linear_regression_check says 0 / RLVI_E_LIMIT without launching).  info[3] == 1: a
+ * pivot of the normal equations was not safely positive (rank-deficient design, non-finite data); theta / weights
+ * are then NOT written and the caller composes rlvi_wls_solve_f64 (minimum-norm solution, as the reference's
+ * lstsq returns) / rlvi_linreg_losses_f64 / rlvi_update_weights_f64 itself, as for shapes beyond the limit.
+ * ------------------------------------------------------------------------------------- */
+int rlvi_linear_regression_check(int64_t n, int64_t d);
+int rlvi_linear_regression_f64(const double *X, const double *y, int64_t n, int64_t d, int maxiter, double tol,
+                               double estep_tol, int estep_maxiter, double *theta, double *weights,
+                               int32_t *info, void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One mini-batch of the online path in ONE launch, replaces online-learning/main.py:293-297:
+ *   log_proba = log(0.5) for the first batch (first != 0; X, w may be NULL), else clf.predict_log_proba(X)[:, 1]
+ *   = log sigmoid(X w + b) (:295, X.w on the fp64 matrix cores); residuals = -log_proba (:296 with :84-85: the
+ *   target does not enter); sample_weight = update_weights_rlvi(residuals, tol, maxiter) (:297 -> :45-58).
+ *   losses_out [n] (may be NULL) receives the residuals, out_iters (may be NULL) the iterations.  n <= 4096.
+ * ------------------------------------------------------------------------------------- */
+int rlvi_sample_weight_online_f64(const double *X, const double *w, double b, int first, int64_t n, int64_t d,
+                                  double tol, int maxiter, double *losses_out, double *sample_weight,
+                                  int32_t *out_iters, void *stream);
+
+/* Measurement aid (bench.py: roofline.copy_same_bytes_us): flat copy, 16 B per lane, nontemporal loads and stores,
+ * 16 waves per CU -- the plainest kernel that moves the M-step's bytes.  16-byte aligned, bytes a multiple of 16. */
+int rlvi_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

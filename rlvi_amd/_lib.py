@@ -21,12 +21,17 @@ SIGNATURES = {
     "rlvi_abi_version": (_int, []),
     "rlvi_error_string": (ctypes.c_char_p, [_int]),
     "rlvi_tune_set": (_int, [ctypes.c_char_p, _int]),
+    "rlvi_tune_unset": (_int, [ctypes.c_char_p]),
+    "rlvi_tune_overrides": (_int, [ctypes.c_char_p, _int]),
     "rlvi_device_cus": (_int, []),
     "rlvi_device_pci_bus_id": (_int, [ctypes.c_char_p, _int]),
     "rlvi_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "rlvi_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
     "rlvi_workspace_status": (_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "rlvi_workspace_clear_status": (_int, [_vp, _vp]),
+    "rlvi_workspace_set_option": (_int, [_vp, ctypes.c_char_p, _int]),
+    "rlvi_workspace_reset_warm": (_int, [_vp, _vp]),
+    "rlvi_workspace_region": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]),
     "rlvi_peer_inbox_bytes": (ctypes.c_size_t, []),
     "rlvi_peer_alloc": (_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "rlvi_peer_free": (_int, [_vp]),
@@ -58,10 +63,14 @@ SIGNATURES = {
     "rlvi_wls_solve_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "rlvi_linreg_losses_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_logistic_nll_f64": (_int, [_vp, _vp, _f64, _i64, _i64, _vp, _vp]),
+    "rlvi_linear_regression_check": (_int, [_i64, _i64]),
+    "rlvi_linear_regression_f64": (_int, [_vp, _vp, _i64, _i64, _int, _f64, _f64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "rlvi_sample_weight_online_f64": (_int, [_vp, _vp, _f64, _int, _i64, _i64, _f64, _int, _vp, _vp, _vp, _vp]),
+    "rlvi_stream_copy": (_int, [_vp, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None
-ABI_VERSION = 2          # RLVI_ABI_VERSION of include/rlvi_hip.h
+ABI_VERSION = 3          # RLVI_ABI_VERSION of include/rlvi_hip.h
 
 
 class RlviError(RuntimeError):
@@ -104,6 +113,13 @@ def load():
         raise RlviError("librlvi_gfx950.so ABI version mismatch")
     _lib = L
     return L
+
+
+def tune_overrides():
+    """Names of the process-wide knobs that carry a rlvi_tune_set value right now."""
+    buf = ctypes.create_string_buffer(4096)
+    n = load().rlvi_tune_overrides(buf, len(buf))
+    return [s for s in buf.value.decode().split(",") if s] if n else []
 
 
 def check(rc, what):

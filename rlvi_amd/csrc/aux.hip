@@ -1,5 +1,7 @@
 // Workspace management, error strings, the in-batch E+M composition and the fp64 X.theta
 // per-sample NLL kernels of the linear / logistic paths.
+#include <string.h>
+
 #include "rlvi_common.h"
 
 using namespace rlvi;
@@ -44,10 +46,34 @@ extern "C" int rlvi_workspace_init(void *ws, size_t ws_bytes, void *stream) {
     e = hipMemsetAsync(static_cast<char *>(ws) + WS_FEREC_OFF, 0, WS_FEREC_BYTES + WS_PEER_BYTES, st);
     if (e != hipSuccess) return (int)e;
     peers_forget(ws);
+    ws_options_forget(ws);
     // bound of every inter-workgroup wait (RLVI_SPIN_BOUND_MS, default 100 ms), in 100 MHz ticks
     const long long ms = tune_get("RLVI_SPIN_BOUND_MS", 100);
     const unsigned long long ticks = (unsigned long long)(ms > 0 ? ms : 100) * 100000ull;
     return launch(ws_header_kernel, dim3(1), dim3(1), 0, st, static_cast<WsHeader *>(ws), ticks, 0);
+}
+
+// Byte offset (and size) of a named region of the workspace layout -- for tools and tests that look at what the
+// kernels leave there: "records" (accumulate-mode M-step records), "records_out" (records of calls with `out`),
+// "warm" (warm-start state of the E-step / threshold), "scratch".  (size_t)-1 for an unknown name.
+extern "C" size_t rlvi_workspace_region(const char *name, size_t *bytes) {
+    size_t off = (size_t)-1, n = 0;
+    if (name && strcmp(name, "records") == 0) { off = WS_PART_OFF; n = WS_PART_BYTES; }
+    else if (name && strcmp(name, "records_out") == 0) { off = WS_PART2_OFF; n = WS_PART_BYTES; }
+    else if (name && strcmp(name, "warm") == 0) { off = WS_TRAJ_OFF; n = WS_TRAJ_BYTES; }
+    else if (name && strcmp(name, "scratch") == 0) { off = WS_SCRATCH_OFF; n = 0; }
+    if (bytes) *bytes = n;
+    return off;
+}
+
+// Forget what earlier calls left as guesses for the next one (the E-step's trajectory and minimum, the
+// threshold's key): the next E-step / threshold on this workspace starts as on a fresh one.  Results never
+// depend on the guesses -- only the number of rounds / exchanges does.
+extern "C" int rlvi_workspace_reset_warm(void *ws, void *stream) {
+    if (!ws) return RLVI_E_NULL;
+    if (((uintptr_t)ws & 255)) return RLVI_E_ALIGN;
+    return (int)hipMemsetAsync(static_cast<char *>(ws) + WS_TRAJ_OFF, 0, WS_TRAJ_BYTES,
+                               static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rlvi_workspace_clear_status(void *ws, void *stream) {
@@ -309,4 +335,31 @@ extern "C" int rlvi_logistic_nll_f64(const double *X, const double *w, double b,
     }
     return mfma ? launch(logistic_nll_kernel<true>, dim3(nb), dim3(256), 0, st, X, w, b, n, d, losses)
                 : launch(logistic_nll_kernel<false>, dim3(nb), dim3(256), 0, st, X, w, b, n, d, losses);
+}
+
+// ---------------------------------------------------------------------------------------
+// Measurement aid (bench.py's roofline.copy_same_bytes_us): a flat copy, 16 bytes per lane, nontemporal loads
+// and stores, one 16-byte piece per lane and trip, grid = 16 waves per CU -- the plainest kernel that moves the
+// M-step's bytes (logits in, gradient out), timed in the same rotation and graph as the M-step itself.
+// ---------------------------------------------------------------------------------------
+namespace rlvi {
+typedef unsigned int aux_vu4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(aux_vu4 *__restrict__ dst, const aux_vu4 *__restrict__ src,
+                                                          int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+}  // namespace rlvi
+
+extern "C" int rlvi_stream_copy(void *dst, const void *src, size_t bytes, void *stream) {
+    if (!dst || !src) return RLVI_E_NULL;
+    if (((uintptr_t)dst & 15) || ((uintptr_t)src & 15) || (bytes & 15)) return RLVI_E_ALIGN;
+    if (bytes == 0) return 0;
+    const int64_t n16 = (int64_t)(bytes / 16);
+    int64_t nb = (n16 + 255) / 256;
+    const int64_t cap = (int64_t)device_info().cus * 4 * tune_get("RLVI_COPY_WPS", 4);     // 16 waves per CU
+    if (nb > cap) nb = cap;
+    return launch(stream_copy_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream),
+                  static_cast<aux_vu4 *>(dst), static_cast<const aux_vu4 *>(src), n16);
 }

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 
 #include "rlvi_common.h"
 
@@ -135,6 +136,73 @@ extern "C" int rlvi_tune_set(const char *name, int value) {
         return 0;
     }
     return rlvi::add(name, value, true) ? 0 : RLVI_E_LIMIT;
+}
+
+// Forget a value set by rlvi_tune_set: the knob is its environment variable / built-in default again.
+// Returns 1 if there was such a value, 0 if not.
+extern "C" int rlvi_tune_unset(const char *name) {
+    if (!name) return RLVI_E_NULL;
+    std::lock_guard<std::mutex> lk(rlvi::g_mu);
+    rlvi::Knob *k = rlvi::find(name);
+    if (!k || !k->from_set) return 0;
+    *k = rlvi::g_knobs[--rlvi::g_nknobs];       // (order is irrelevant)
+    return 1;
+}
+
+// Names of the knobs that currently carry a rlvi_tune_set value, comma-separated, into buf[len] (cut at len - 1);
+// returns how many there are.  A test harness asserts 0 after every test: a knob is process-wide, and one that
+// a test forgot to take back changes which kernel every later call runs.
+extern "C" int rlvi_tune_overrides(char *buf, int len) {
+    std::lock_guard<std::mutex> lk(rlvi::g_mu);
+    int n = 0;
+    size_t pos = 0;
+    if (buf && len > 0) buf[0] = 0;
+    for (int i = 0; i < rlvi::g_nknobs; ++i) {
+        if (!rlvi::g_knobs[i].from_set) continue;
+        ++n;
+        if (!buf || len <= 0) continue;
+        const size_t l = strlen(rlvi::g_knobs[i].name);
+        if (pos + l + 2 < (size_t)len) {
+            if (pos) buf[pos++] = ',';
+            memcpy(buf + pos, rlvi::g_knobs[i].name, l);
+            pos += l;
+            buf[pos] = 0;
+        }
+    }
+    return n;
+}
+
+// ---- per-workspace launch options (host side: what a launcher needs to know about the CALLER of this workspace,
+// as opposed to the process-wide tuning knobs above)
+namespace rlvi {
+namespace {
+struct WsOptions { int v[WSOPT_COUNT]; bool set[WSOPT_COUNT]; };
+std::unordered_map<const void *, WsOptions> g_wsopt;
+std::mutex g_wsopt_mu;
+}  // namespace
+int ws_option(const void *ws, int which, int dflt) {
+    if (which < 0 || which >= WSOPT_COUNT) return dflt;
+    std::lock_guard<std::mutex> lk(g_wsopt_mu);
+    auto it = g_wsopt.find(ws);
+    return (it != g_wsopt.end() && it->second.set[which]) ? it->second.v[which] : dflt;
+}
+void ws_options_forget(const void *ws) {
+    std::lock_guard<std::mutex> lk(g_wsopt_mu);
+    g_wsopt.erase(ws);
+}
+}  // namespace rlvi
+
+extern "C" int rlvi_workspace_set_option(void *ws, const char *name, int value) {
+    if (!ws || !name) return RLVI_E_NULL;
+    int which = -1;
+    if (strcmp(name, "logits_from_hbm") == 0) which = rlvi::WSOPT_LOGITS_FROM_HBM;
+    else if (strcmp(name, "cold_start") == 0) which = rlvi::WSOPT_COLD_START;
+    if (which < 0) return RLVI_E_SHAPE;
+    std::lock_guard<std::mutex> lk(rlvi::g_wsopt_mu);
+    rlvi::WsOptions &o = rlvi::g_wsopt[ws];
+    o.v[which] = value;
+    o.set[which] = true;
+    return 0;
 }
 
 extern "C" int rlvi_device_cus(void) { return rlvi::device_info().cus; }

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMP
     const int64_t hi = lo + L < N ? lo + L : N;
     // (sharded over several GPUs: N samples here, Nall over all ranks, pt the peers' inboxes;
     //  otherwise Nall == N and pt == nullptr)
-    const TbWarm wm = tb_warm(ws, Nall, K, pt != nullptr);
+    // (verify bit 1: the caller asked for a cold start -- the workspace option "cold_start": no guess from the last call)
+    const TbWarm wm = tb_warm(ws, Nall, K, pt != nullptr, (verify & 2) != 0);
 
     // ---- slice -> registers: raw residuals and the caller's pi
     float l[E], ev[E], q0[E];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(TB_BLOCK, (TB_BLOCK == 256 && E == 1 && !RLVI_STAMP
         q0[j] = ok ? wts[i] : 0.0f;
     }
     const TbSolved s = trajb_solve<E, TB_BLOCK>(sh, wm, l, q0, ev, true, b, G, Nall, tol, K, out_iters, trace,
-                                                ws, dbg, pt, verify != 0, mstep_out, mstep_scale);
+                                                ws, dbg, pt, (verify & 1) != 0, mstep_out, mstep_scale);
     // a wait that timed out (RLVI_ST_TIMEOUT: the workgroups were not all resident) leaves the
     // caller's residuals and pi as they were -- the host raises on the status; it never hands out garbage
 #if RLVI_STAMPS
@@ -114,7 +115,10 @@ int try_launch_estep_trajb(float *res, float *wts, int64_t N, float tol, int max
     unsigned long long *dbg = (debug && !dry_run) ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF) : nullptr;
     const int64_t Nall = sharded ? n_all : N;
     PeerTable *pt = (sharded && !dry_run) ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
-    const int verify = tune_get("RLVI_TJ_VERIFY", 0);      // 1: always run the verification round
+    // bit 0: always run the verification round (lab knob); bit 1: ignore the previous call's trajectory (the
+    // caller's workspace option "cold_start": every call as the reference's loop starts it, train_rlvi.py:29)
+    const int verify = (tune_get("RLVI_TJ_VERIFY", 0) ? 1 : 0) |
+                       ((!sharded && !dry_run && ws_option(ws, WSOPT_COLD_START, 0)) ? 2 : 0);
     int launched = 0;
     // The exchanging workgroups wait for each other, so all of them (and the reduction workgroup) must
     // be resident at once: a geometry (E samples per thread, B threads) runs on G = min(TB_G, what

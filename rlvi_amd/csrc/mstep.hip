@@ -658,7 +658,8 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
     int form = tune_get("RLVI_MSTEP_FORM", -1);
     if (form < 0) form = (B + R - 1) / R > 512 ? 1 : 0;
     char *base = static_cast<char *>(ws);
-    double *part = reinterpret_cast<double *>(base + WS_PART_OFF);
+    // (a call with `out` has records of its own: it never touches what an accumulate sequence has piled up)
+    double *part = reinterpret_cast<double *>(base + (out == nullptr ? WS_PART_OFF : WS_PART2_OFF));
     int32_t *status = reinterpret_cast<int32_t *>(base);
     const int accum = out == nullptr ? 1 : 0;       // no `out`: accumulate for rlvi_epoch_end_f32
     const double inv_rows100 = 100.0 / (double)B;
@@ -688,7 +689,10 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         // than the hold assumes, and the hold then COSTS time (single buffer pair: 9.4 -> 10.3 us): the
         // caller knows which case it is in, the kernel does not (a per-CU barrier between reads and writes
         // -- 16-wave workgroups -- was built to let the data decide: no gain cold, 9.4 -> 10.1 us warm).
-        int hold_ticks = tune_get("RLVI_MSTEP_HOLD", 0);
+        // (the caller's hint lives with the caller's workspace -- rlvi_workspace_set_option(ws, "logits_from_hbm", 1)
+        //  -- not with the process: two training loops, or two streams, do not see each other's; the knob of the
+        //  same meaning is the lab override)
+        int hold_ticks = tune_get("RLVI_MSTEP_HOLD", ws_option(ws, WSOPT_LOGITS_FROM_HBM, 0) ? -1 : 0);
         int gen_ticks = tune_get("RLVI_MSTEP_GEN", -1);      // ticks between the holds of successive tile generations
         const int64_t waves = nb * WPB;
         const double gen_bytes = (double)(nfull < waves ? nfull : waves) * (double)wtile_bytes;

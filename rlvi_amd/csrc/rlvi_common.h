@@ -30,6 +30,10 @@ struct DeviceInfo {
 const DeviceInfo &device_info();
 // Integer knob: rlvi_tune_set() value, else the environment variable of that name, else dflt.
 int tune_get(const char *name, int dflt);
+// Per-workspace launch option (rlvi_workspace_set_option), else dflt.  Host side only: the launchers ask it.
+enum { WSOPT_LOGITS_FROM_HBM = 0, WSOPT_COLD_START = 1, WSOPT_COUNT = 2 };
+int ws_option(const void *ws, int which, int dflt);
+void ws_options_forget(const void *ws);
 // Workgroups that are provably co-resident given the occupancy API's answer for one CU.
 int coop_blocks_from_occupancy(int per_cu_api, int block_threads, int cus);
 // Number of co-resident workgroups of `kernel` (block threads, dynamic LDS bytes) on this device.
@@ -97,7 +101,10 @@ constexpr size_t WS_PART_BYTES = (size_t)MSTEP_MAX_BLOCKS * PART_STRIDE * 8;
 // third exchange region (trajectory E-step, estep_trajb.hip), 64-byte records of eight self-tagged
 // fp32 granules {S, P, Q, D, min, R3, R4, -}: stage A [2 parities][64 nodes][256 workgroups], stage B [2][64 nodes]
 constexpr int XCHG3_GRANULES = 8;
-constexpr size_t WS_XCHG3A_OFF = WS_PART_OFF + WS_PART_BYTES;
+// a second set of records for calls WITH `out` (their own finalize launch reduces and clears them): such a call may
+// be interleaved with an accumulate sequence on the same workspace without touching its records
+constexpr size_t WS_PART2_OFF = WS_PART_OFF + WS_PART_BYTES;
+constexpr size_t WS_XCHG3A_OFF = WS_PART2_OFF + WS_PART_BYTES;
 constexpr size_t WS_XCHG3A_BYTES = 2ull * 64 * MAX_COOP_WG * XCHG3_GRANULES * 8;   // 2 MiB
 constexpr size_t WS_XCHG3B_OFF = WS_XCHG3A_OFF + WS_XCHG3A_BYTES;
 #ifndef RLVI_XCHG3B_REPLICAS

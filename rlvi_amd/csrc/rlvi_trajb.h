@@ -126,12 +126,12 @@ struct TbWarm {
     float rn_l;       // lane k: guessed node k
     int it;
 };
-__device__ __forceinline__ TbWarm tb_warm(void *ws, int64_t N, int K, bool sharded = false) {
+__device__ __forceinline__ TbWarm tb_warm(void *ws, int64_t N, int K, bool sharded = false, bool cold = false) {
     const TrajState *state = reinterpret_cast<const TrajState *>(static_cast<char *>(ws) +
                                                                  (sharded ? WS_PEER_STATE_OFF : WS_TRAJ_OFF));
     const int lane = threadIdx.x & (WAVE - 1);
     TbWarm w;
-    w.warm = state->n == (long long)N && state->k == K;
+    w.warm = !cold && state->n == (long long)N && state->k == K;
     w.shift = w.warm ? state->shift : 0.0f;
     w.rn_l = lane < K ? (w.warm ? state->nodes[lane] : 19.0f * exp2f(-(float)lane)) : 1.0f;
     if (lane == 0) w.rn_l = (float)(0.95 / (1.0 - 0.95));

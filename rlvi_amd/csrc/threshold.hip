@@ -952,7 +952,8 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
                                   : nullptr;
     int rc = RLVI_E_LIMIT;
     bool launched = false;
-    const int use_state = tune_get("RLVI_THR_WARM", 1);      // 0: never use the last call's key as a guess
+    // 0: never use the last call's key as a guess (lab knob; the caller's form: the workspace option "cold_start")
+    const int use_state = tune_get("RLVI_THR_WARM", (!sharded && ws_option(ws, WSOPT_COLD_START, 0)) ? 0 : 1);
     // key-list finish once at most this many keys PER WORKGROUP (on average) are left inside the prefix; 0: never
     const int list_per_wg = tune_get("RLVI_THR_LIST", 4);
 #define RLVI_THQ(E_, G_)                                                                         \

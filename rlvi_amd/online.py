@@ -35,15 +35,34 @@ def residuals(X, coef, intercept):
     return ops.logistic_nll(Xd, wd, float(intercept)).cpu().numpy()
 
 
-def rlvi_sample_weight(X, coef=None, intercept=0.0):
+def rlvi_sample_weight(X, coef=None, intercept=0.0, tol=1e-3, maxiter=100):
     """sample_weight for clf.partial_fit (main.py:291-299).  coef None = classifier not fitted
-    yet: log_proba = log(0.5) for every row (main.py:293)."""
+    yet: log_proba = log(0.5) for every row (main.py:293).
+    One launch (rlvi_sample_weight_online_f64: X.coef on the fp64 matrix cores -> -log sigmoid -> the online
+    E-step) between one pinned H2D copy of [X | coef] and one pinned D2H copy; the host waits once.  Batches of
+    more than 4096 rows take the two-launch composition."""
+    from .standard import _STAGE
     dev = _dev()
-    if coef is None:
-        l = torch.full((len(X),), float(-np.log(0.5)), dtype=torch.float64, device=dev)
-    else:
-        Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
-        wd = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64).ravel()).to(dev)
-        l = ops.logistic_nll(Xd, wd, float(intercept))
-    w, _ = ops.update_weights_f64(l, online=True)
-    return w.cpu().numpy()
+    n = len(X)
+    first = coef is None
+    if n > 4096:
+        if first:
+            l = torch.full((n,), float(-np.log(0.5)), dtype=torch.float64, device=dev)
+        else:
+            Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
+            wd = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64).ravel()).to(dev)
+            l = ops.logistic_nll(Xd, wd, float(intercept))
+        w, _ = ops.update_weights_f64(l, tol=tol, maxiter=maxiter, online=True)
+        return w.cpu().numpy()
+    Xh = np.ascontiguousarray(X, dtype=np.float64)
+    d = Xh.shape[1] if Xh.ndim == 2 else 1
+    h_in, h_out = _STAGE.get(dev, "online", (n * d + d, n))
+    if not first:
+        h_in.numpy()[:n * d] = Xh.reshape(-1)
+        h_in.numpy()[n * d:] = np.ascontiguousarray(coef, dtype=np.float64).ravel()
+    d_in = h_in.to(dev, non_blocking=True) if not first else torch.empty(n * d + d, dtype=torch.float64, device=dev)
+    d_out, _, _ = ops.sample_weight_online(d_in[:n * d].view(n, d), d_in[n * d:], float(intercept), first=first,
+                                           tol=tol, maxiter=maxiter)
+    h_out.copy_(d_out, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    return h_out.numpy()[:n].copy()

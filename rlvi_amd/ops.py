@@ -58,6 +58,29 @@ class Workspace:
         _lib.check(_lib.load().rlvi_workspace_clear_status(self.ptr, _stream_ptr()),
                    "rlvi_workspace_clear_status")
 
+    def set_option(self, name, value):
+        """Per-workspace launch option (include/rlvi_hip.h, rlvi_workspace_set_option): "logits_from_hbm",
+        "cold_start".  Host side, from the next launch on this workspace on."""
+        _lib.check(_lib.load().rlvi_workspace_set_option(self.ptr, name.encode(), int(value)),
+                   f"rlvi_workspace_set_option({name})")
+
+    def reset_warm(self):
+        """Forget the guesses the last E-step / threshold left for the next one."""
+        _lib.check(_lib.load().rlvi_workspace_reset_warm(self.ptr, _stream_ptr()), "rlvi_workspace_reset_warm")
+
+    def region(self, name):
+        """(offset, bytes) of a named region of the layout ("records", "records_out", "warm", "scratch")."""
+        n = ctypes.c_size_t(0)
+        off = int(_lib.load().rlvi_workspace_region(name.encode(), ctypes.byref(n)))
+        if off == ctypes.c_size_t(-1).value:
+            raise ValueError(f"unknown workspace region {name!r}")
+        return off, int(n.value)
+
+    def pending_records(self):
+        """True if accumulate-mode M-step records are waiting for an epoch_end / mstep_reduce (synchronises)."""
+        off, n = self.region("records")
+        return bool(self.buf[off:off + n].view(torch.float64).ne(0).any().item())
+
     def raise_on_status(self, what, mask=_lib.ST_RANGE | _lib.ST_TIMEOUT | _lib.ST_NOCONV):
         """Read the sticky device status (one 4-byte copy + stream sync) and raise RlviError on any
         flag of `mask`; the flag is cleared first so that the caller can recover and go on."""
@@ -135,17 +158,17 @@ def mstep_fwd_bwd(logits, labels, idx, weights, residuals, inv_scale=None, want_
     return out, grad
 
 
-def hint_logits_from_hbm(flag=True):
-    """Tell the M-step launcher where its logits come from (process-wide, from the next launch on).
+def hint_logits_from_hbm(ws, flag=True):
+    """Tell the M-step launcher where the logits of the calls ON THIS WORKSPACE come from.
 
-    True: the [B, C] block streams from HBM -- it is larger than the Infinity Cache, or (bench.py) one of
-    many blocks touched in rotation.  A one-tile-per-wave launch of 12 MB and more then holds its gradient
-    stores until its reads have had their time at the HBM read rate (reads first, then writes, chip-wide:
-    mstep.hip), 11.8 -> 10.7 us at 65 536 x 100.  False (the default): nothing is assumed -- a chip-filling
-    launch separates its reads from its writes per CU with a barrier behind the issue of its loads (10.9 us
-    from HBM, 9.3 us from the cache); the timed hold would cost time on a block that the model's last layer
-    has just written and the cache serves (9.4 -> 10.3 us), which is what train_rlvi sees."""
-    _lib.check(_lib.load().rlvi_tune_set(b"RLVI_MSTEP_HOLD", -1 if flag else 0), "rlvi_tune_set")
+    True: the [B, C] block streams from HBM -- it is larger than the Infinity Cache, or one of many blocks
+    touched in rotation.  A one-tile-per-wave launch of 12 MB and more then holds its gradient stores until its
+    reads have had their time at the HBM read rate (reads first, then writes, chip-wide: mstep.hip).  False (the
+    default): nothing is assumed -- a chip-filling launch separates its reads from its writes per CU with a
+    barrier behind the issue of its loads; the timed hold would cost time on a block that the model's last
+    layer has just written and the cache serves (9.4 -> 10.3 us), which is what train_rlvi sees.
+    Per workspace (round 3 had a process-wide knob): two loops on two streams do not see each other's hint."""
+    ws.set_option("logits_from_hbm", 1 if flag else 0)
 
 
 class MStepLoop:
@@ -172,16 +195,22 @@ class MStepLoop:
         self.N = weights.shape[0]
         self.ws = ws or workspace(weights.device, self.N, 0)
         self._w, self._r, self._wsp = weights.data_ptr(), residuals.data_ptr(), self.ws.buf.data_ptr()
-        self._stream = torch.cuda.current_stream().cuda_stream
+        self._stream = torch.cuda.current_stream(weights.device).cuda_stream
         self._f32, self._bf16 = L.rlvi_mstep_fwd_bwd_f32, L.rlvi_mstep_fwd_bwd_bf16
         self._grads = {}
         self._dev = weights.device
 
     def __call__(self, logits, labels, idx, inv_scale=None):
         dt = logits.dtype
-        if not (logits.dim() == 2 and (dt is torch.float32 or dt is torch.bfloat16) and logits.is_contiguous()
-                and labels.dtype is torch.int64 and idx.dtype is torch.int64 and labels.is_cuda and idx.is_cuda
-                and logits.is_cuda and labels.is_contiguous() and idx.is_contiguous()):
+        # the validated form, on the device and the stream the loop was made on; anything else -- strided or
+        # other-typed logits, no index vector, a tensor on another device, a caller that has switched streams
+        # inside the epoch -- takes the generic, fully checked wrapper (which launches on the CURRENT stream)
+        if not (idx is not None and logits.dim() == 2 and (dt is torch.float32 or dt is torch.bfloat16)
+                and logits.is_contiguous() and labels.dtype is torch.int64 and idx.dtype is torch.int64
+                and logits.device == self._dev and labels.device == self._dev and idx.device == self._dev
+                and labels.is_contiguous() and idx.is_contiguous()
+                and torch.cuda.current_stream(self._dev).cuda_stream == self._stream):
+            _require_gpu(logits, labels, idx)
             _, grad = mstep_fwd_bwd(logits.detach(), labels, idx, self.weights, self.residuals,
                                     inv_scale=inv_scale, accumulate=True, ws=self.ws)
             return grad
@@ -192,7 +221,8 @@ class MStepLoop:
             grad = self._grads[key] = torch.empty((B, C), dtype=dt, device=self._dev)
         rc = (self._f32 if dt is torch.float32 else self._bf16)(
             logits.data_ptr(), C, labels.data_ptr(), idx.data_ptr(), self._w, self._r, self.N, B, C,
-            inv_scale if inv_scale is not None else 1.0 / B, grad.data_ptr(), C, None, self._wsp, self._stream)
+            float(inv_scale) if inv_scale is not None else 1.0 / B, grad.data_ptr(), C, None, self._wsp,
+            self._stream)
         if rc:
             _lib.check(rc, "rlvi_mstep_fwd_bwd")
         return grad
@@ -443,6 +473,61 @@ def logistic_nll(X, w, b):
                                        n, d, _ptr(losses), _stream_ptr()),
                "rlvi_logistic_nll_f64")
     return losses
+
+
+def linear_regression_check(n, d):
+    """True if rlvi_linear_regression_f64 takes an [n, d] design in its one-launch form."""
+    return _lib.load().rlvi_linear_regression_check(int(n), int(d)) == 0
+
+
+def linear_regression(X, y, maxiter=100, tol=1e-3, estep_tol=1e-3, estep_maxiter=100, theta=None, weights=None,
+                      info=None, ws=None):
+    """linear_regression(X, y, maxiter, tol) of standard-learning/rlvi.py:68-89 as ONE launch on device tensors
+    (no host synchronisation here).  Returns (theta [d], weights [n], info int32[4] = {outer iterations, inner
+    iterations of the last E-step, inner iterations in all, fallback}) -- info[3] == 1 (rank-deficient design):
+    theta / weights were not written, compose wls_solve / linreg_losses / update_weights_f64 instead."""
+    L = _lib.load()
+    _require_gpu(X, y)
+    if X.dtype != torch.float64 or y.dtype != torch.float64 or not X.is_contiguous() or not y.is_contiguous():
+        raise ValueError("X [n, d] and y [n] must be contiguous fp64 device tensors")
+    n, d = X.shape
+    if theta is None:
+        theta = torch.empty(d, dtype=torch.float64, device=X.device)
+    if weights is None:
+        weights = torch.empty(n, dtype=torch.float64, device=X.device)
+    if info is None:
+        info = torch.zeros(4, dtype=torch.int32, device=X.device)
+    ws = ws or workspace(X.device, n, 0)
+    _lib.check(L.rlvi_linear_regression_f64(_ptr(X), _ptr(y), n, d, int(maxiter), float(tol), float(estep_tol),
+                                            int(estep_maxiter), _ptr(theta), _ptr(weights), _ptr(info), ws.ptr,
+                                            _stream_ptr()), "rlvi_linear_regression_f64")
+    return theta, weights, info
+
+
+def sample_weight_online(X, coef, intercept=0.0, first=False, tol=1e-3, maxiter=100, out=None, losses=None,
+                         iters=None):
+    """One mini-batch of online-learning/main.py:293-297 in ONE launch on device tensors: residuals =
+    -log sigmoid(X coef + intercept) (log 2 for the first batch), sample_weight = update_weights_rlvi(residuals).
+    Returns (sample_weight [n], losses or None, iters or None)."""
+    L = _lib.load()
+    _require_gpu(X, coef)
+    n, d = X.shape
+    if not first and (X.dtype != torch.float64 or not X.is_contiguous() or coef.dtype != torch.float64):
+        raise ValueError("X [n, d] and coef [d] must be contiguous fp64 device tensors")
+    if out is None:
+        out = torch.empty(n, dtype=torch.float64, device=X.device)
+    _lib.check(L.rlvi_sample_weight_online_f64(_ptr(X), _ptr(coef), float(intercept), 1 if first else 0, n, d,
+                                               float(tol), int(maxiter), _ptr(losses), _ptr(out), _ptr(iters),
+                                               _stream_ptr()), "rlvi_sample_weight_online_f64")
+    return out, losses, iters
+
+
+def stream_copy(dst, src):
+    """Measurement aid: flat nontemporal 16-B/lane copy of src into dst (same byte count, 16-byte multiples)."""
+    nbytes = src.numel() * src.element_size()
+    if dst.numel() * dst.element_size() != nbytes:
+        raise ValueError("stream_copy: sizes differ")
+    _lib.check(_lib.load().rlvi_stream_copy(_ptr(dst), _ptr(src), nbytes, _stream_ptr()), "rlvi_stream_copy")
 
 
 class _WeightedCE(torch.autograd.Function):

@@ -25,29 +25,54 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-_STAGE = {}
+class _Staging:
+    """Pinned host buffers for the numpy-in / numpy-out calls: one set per (thread, device, tag, sizes), least
+    recently used evicted beyond 32 sets.  Keyed by the thread as well: the buffers are written, copied
+    asynchronously and read back around ONE host wait, so two threads must never share a set."""
+
+    def __init__(self, cap=32):
+        import collections
+        import threading
+        self._lock = threading.Lock()
+        self._sets = collections.OrderedDict()
+        self._cap = cap
+
+    def get(self, dev, tag, sizes, dtype=torch.float64):
+        import threading
+        key = (threading.get_ident(), dev.index, tag, tuple(int(x) for x in sizes), dtype)
+        with self._lock:
+            st = self._sets.get(key)
+            if st is not None:
+                self._sets.move_to_end(key)
+                return st
+        st = tuple(torch.empty(max(int(x), 1), dtype=dtype).pin_memory() for x in sizes)
+        with self._lock:
+            self._sets[key] = st
+            while len(self._sets) > self._cap:
+                self._sets.popitem(last=False)
+        return st
+
+
+_STAGE = _Staging()
 
 
 def _roundtrip_f64(host_in, fn):
-    """numpy in, numpy out through pinned staging buffers (one pair per length, kept): both copies are queued on
-    the stream around the launch and the host waits ONCE -- a pageable `.to(device)` and a `.cpu()` are two
-    synchronising copies of their own (update_weights at n = 40 ... 1000: 60-66 -> 51-54 us per call; the fp64
-    iterative kernel and four torch calls are the rest)."""
+    """numpy in, numpy out through pinned staging buffers: both copies are queued on the stream around the
+    launch and the host waits ONCE -- a pageable `.to(device)` and a `.cpu()` are two synchronising copies of
+    their own (update_weights at n = 40 ... 1000: 60-66 -> 51-54 us per call; the fp64 iterative kernel and four
+    torch calls are the rest).  The result has the input's shape."""
     dev = _dev()
-    a = np.ascontiguousarray(host_in, dtype=np.float64).reshape(-1)
-    st = _STAGE.get((dev.index, a.size))
-    if st is None:
-        st = (torch.empty(a.size, dtype=torch.float64).pin_memory(),
-              torch.empty(a.size, dtype=torch.float64).pin_memory())
-        if len(_STAGE) >= 64:
-            _STAGE.clear()
-        _STAGE[(dev.index, a.size)] = st
-    h_in, h_out = st
+    a = np.ascontiguousarray(host_in, dtype=np.float64)
+    shape = a.shape
+    a = a.reshape(-1)
+    if a.size == 0:
+        return np.empty(shape, np.float64)
+    h_in, h_out = _STAGE.get(dev, "roundtrip", (a.size, a.size))
     h_in.numpy()[:] = a
     d_out = fn(h_in.to(dev, non_blocking=True))
     h_out.copy_(d_out, non_blocking=True)
     torch.cuda.current_stream(dev).synchronize()
-    return h_out.numpy().copy()
+    return h_out.numpy().copy().reshape(shape)
 
 
 def update_weights(losses, tol=1e-3, maxiter=100):
@@ -67,10 +92,11 @@ def _wls(X, y, w):
     return sol.solution[:, 0]
 
 
-def linear_regression(X, y, maxiter=100, tol=1e-3, return_info=False):
-    dev = _dev()
-    X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
-    y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(dev)
+def _linear_regression_host_loop(X, y, maxiter, tol):
+    """The general path (any n, d <= 63 on the device solver, rank-deficient designs through the minimum-norm
+    kernel): one launch per statement of rlvi.py:76-87 and the stop test on the host, one sync per outer
+    iteration.  X, y: device tensors."""
+    dev = X.device
     w = torch.ones(X.shape[0], dtype=torch.float64, device=dev)
     theta = _wls(X, y, w)
     losses, _ = ops.linreg_losses(X, y, theta, w)          # rlvi.py:72-74
@@ -84,9 +110,44 @@ def linear_regression(X, y, maxiter=100, tol=1e-3, return_info=False):
         disc = torch.linalg.norm(theta - prev) / torch.linalg.norm(prev)
         if bool(disc <= tol):                               # rlvi.py:85-87 (one host sync)
             break
+    return theta, w, outer
+
+
+def linear_regression(X, y, maxiter=100, tol=1e-3, return_info=False):
+    """rlvi.py:68-89.  n <= 4096, d <= 31 (the reference's 40 x 10, BASELINE's 1000 x 20): the whole estimator is
+    ONE launch (rlvi_linear_regression_f64: E-step, weighted least squares on the fp64 matrix cores, NLL and
+    the stop test ||theta - prev|| / ||prev|| <= tol all on the device) between one pinned H2D copy of [X | y]
+    and one pinned D2H copy of {theta, weights, info}; the host waits once.  Beyond that, or when the launch
+    reports a rank-deficient design: the general path."""
+    dev = _dev()
+    Xh = np.ascontiguousarray(X, dtype=np.float64)
+    yh = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+    n, d = Xh.shape
+    ws = ops.workspace(dev, n, 0)
+    if n > 0 and d > 0 and ops.linear_regression_check(n, d):
+        h_in, h_out = _STAGE.get(dev, "linreg", (n * d + n, d + n + 2))
+        h_in.numpy()[:n * d] = Xh.reshape(-1)
+        h_in.numpy()[n * d:] = yh
+        d_in = h_in.to(dev, non_blocking=True)
+        d_out = torch.empty(d + n + 2, dtype=torch.float64, device=dev)
+        info = d_out[d + n:].view(torch.int32)              # 4 x int32 behind theta and the weights
+        ops.linear_regression(d_in[:n * d].view(n, d), d_in[n * d:], maxiter=maxiter, tol=tol,
+                              theta=d_out[:d], weights=d_out[d:d + n], info=info, ws=ws)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()        # the one host wait of the call
+        res = h_out.numpy()
+        inf = res[d + n:].view(np.int32)
+        if inf[3] == 0:
+            if return_info:
+                return res[:d].copy(), res[d:d + n].copy(), int(inf[0])
+            return res[:d].copy()
+        Xd, yd = d_in[:n * d].view(n, d), d_in[n * d:]
+    else:
+        Xd, yd = torch.from_numpy(Xh).to(dev), torch.from_numpy(yh).to(dev)
+    theta, w, outer = _linear_regression_host_loop(Xd, yd, maxiter, tol)
     # a cooperating launch that could not run, a fixed point that did not converge: never silent
     # (RLVI_ST_SINGULAR is information: the minimum-norm solution was returned, as lstsq does)
-    ops.workspace(dev).raise_on_status("linear_regression", mask=_lib.ST_TIMEOUT | _lib.ST_NOCONV)
+    ws.raise_on_status("linear_regression", mask=_lib.ST_TIMEOUT | _lib.ST_NOCONV)
     if return_info:
         return theta.cpu().numpy(), w.cpu().numpy(), outer
     return theta.cpu().numpy()

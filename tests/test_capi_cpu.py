@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.rlvi_abi_version() == 2
+    assert lib.rlvi_abi_version() == 3
     assert lib.rlvi_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.rlvi_error_string(code) not in (b"ok", b"unknown rlvi error")

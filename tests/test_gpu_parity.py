@@ -25,6 +25,46 @@ def gpu():
     return torch, ops, torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def no_process_state_left_behind():
+    """Every `rlvi_tune_set` knob is process-wide and the default workspace is shared by every call that is not
+    given one: a test that leaves a knob set, a sticky status or accumulate-mode records behind changes which
+    kernels the LATER tests run and what their epoch ends sweep up (round 3 could not rule that out for a
+    training loop that collapsed once inside the suite and never alone).  Checked after every test."""
+    yield
+    import torch
+    if not torch.cuda.is_available():
+        return
+    from rlvi_amd import _lib, ops
+    # (RLVI_DEVICE_SHARERS is the product's own declaration -- rlvi_amd.dist.declare_device_sharing -- not a test knob)
+    left = [n for n in _lib.tune_overrides() if n != "RLVI_DEVICE_SHARERS"]
+    for name in left:                                  # (take them back so that ONE test is blamed, not all later ones)
+        _lib.load().rlvi_tune_unset(name.encode())
+    torch.cuda.synchronize()
+    dirty = []
+    for key, ws in list(ops._workspaces.items()):
+        st = ws.status()
+        if st:
+            ws.clear_status()
+            dirty.append(f"workspace {key}: sticky status {st}")
+        if ws.pending_records():
+            ops.mstep_reduce(ws=ws)
+            dirty.append(f"workspace {key}: accumulate-mode records without an epoch end")
+    assert not left, f"knobs left set by this test: {left}"
+    assert not dirty, "; ".join(dirty)
+
+
+def tune(name, value):
+    from rlvi_amd import _lib
+    _lib.check(_lib.load().rlvi_tune_set(name.encode(), int(value)), "tune")
+
+
+def untune(*names):
+    from rlvi_amd import _lib
+    for n in names:
+        _lib.load().rlvi_tune_unset(n.encode())
+
+
 def dev_status(ops, dev):
     return ops.workspace(dev).status()
 
@@ -240,7 +280,7 @@ def test_mstep_bench_size_properties_and_oracle(gpu, oracle):
 def test_mstep_reads_then_writes_forms_change_no_bit(gpu, oracle, B):
     """The M-step separates its reads from its writes in two ways (mstep.hip): by default a launch that fills the
     chip with one tile per wave runs 16-wave workgroups with a barrier behind the issue of the tile loads; with
-    ops.hint_logits_from_hbm(True) four-wave workgroups hold their stores for the read time of the block.  Both
+    ops.hint_logits_from_hbm(ws) four-wave workgroups hold their stores for the read time of the block.  Both
     are a matter of WHEN the stores leave, never of what they carry: gradient and residuals are bit-identical
     between the plain four-wave form, the 16-wave form, the timed hold and an absurdly long hold; the batch
     scalars agree to fp64 summation order (the per-workgroup records group the rows differently).  57 365 rows:
@@ -264,8 +304,7 @@ def test_mstep_reads_then_writes_forms_change_no_bit(gpu, oracle, B):
             torch.cuda.synchronize()
             got.append((out.cpu().numpy(), grad.cpu().numpy(), res.cpu().numpy()))
     finally:
-        _lib.check(L.rlvi_tune_set(b"RLVI_MSTEP_CUWIDE", 1), "tune")
-        ops.hint_logits_from_hbm(False)
+        untune("RLVI_MSTEP_CUWIDE", "RLVI_MSTEP_HOLD")
     for o, g, r in got[1:]:
         assert np.array_equal(g, got[0][1]) and np.array_equal(r, got[0][2])
         np.testing.assert_allclose(o, got[0][0], rtol=1e-6)
@@ -379,7 +418,7 @@ def test_estep_golden_without_trace_takes_the_accept_path(key, golden, gpu, orac
             assert ws.status() == 0
             got[verify] = (int(iters), wt.cpu().numpy(), rt.cpu().numpy())
         finally:
-            _lib.check(L.rlvi_tune_set(b"RLVI_TJ_VERIFY", 0), "tune")
+            untune("RLVI_TJ_VERIFY")
     for verify in (0, 1):
         it, wo, ro = got[verify]
         assert it == int(g[key + "/iters"]), (verify, it)
@@ -571,7 +610,7 @@ def test_threshold_key_list_finish_and_its_fallbacks(N, gpu, oracle):
                     assert np.array_equal(mask.cpu().numpy(), m_ref) and int(kept) == int(m_ref.sum()), (name, lst)
                 assert ws.status() == 0
     finally:
-        _lib.check(L.rlvi_tune_set(b"RLVI_THR_LIST", 4), "tune")
+        untune("RLVI_THR_LIST")
 
 
 def test_threshold_randomised_distributions_on_one_workspace(gpu, oracle):
@@ -698,7 +737,7 @@ def test_estep_drifting_inputs_with_and_without_the_accept_shortcut(N, gpu, orac
                 assert ws.status() == 0, (trial, verify)
                 out.append((int(iters), wt.cpu().numpy()))
             finally:
-                _lib.check(L.rlvi_tune_set(b"RLVI_TJ_VERIFY", 0), "tune")
+                untune("RLVI_TJ_VERIFY")
         assert out[0][0] == out[1][0], (trial, out[0][0], out[1][0], it)
         if np.min(np.abs(err - 1e-3)) >= 1e-4 * 1e-3:
             assert out[0][0] == it, (trial, out[0][0], it)
@@ -867,7 +906,7 @@ def _fused_em_run(ops, torch, dev, d, pi0, ws, fused, maxiter=40):
         torch.cuda.synchronize()
         return (out.cpu().numpy(), grad.cpu().numpy(), rows.cpu().numpy(), pit.cpu().numpy(), int(iters))
     finally:
-        _lib.check(L.rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
+        untune("RLVI_FUSED_EM")
 
 
 @pytest.mark.parametrize("B,C", [(65536, 100), (16384, 100), (20000, 100), (65520, 100), (32768, 64),
@@ -1168,6 +1207,98 @@ def test_standard_and_online_mirrors_golden(golden, gpu, oracle):
                                oracle.update_weights_rlvi(oracle.logistic_nll(Xl, wl, b)), rtol=1e-10)
 
 
+@pytest.mark.parametrize("n,d", [(40, 10), (1000, 20), (17, 1), (512, 15), (513, 16), (1024, 23), (1025, 24),
+                                 (3000, 31), (4096, 5), (64, 30), (200, 8)])
+def test_linear_regression_in_one_launch_vs_oracle(n, d, gpu, oracle):
+    """rlvi_linear_regression_f64 (standard.hip): the whole estimator of rlvi.py:68-89 in one launch -- the stop
+    test on the device, one host wait -- against the oracle's restatement (scipy lstsq + the pinned C E-step):
+    theta to 1e-8, the outer-iteration count equal, the final weights, the inner counts plausible; every
+    combination of samples per thread (<= 1024 / beyond), padded system size (16 / 24 / 32) and column tail."""
+    torch, ops, dev = gpu
+    from rlvi_amd import standard
+    X, y = synth.linreg_data(n, d, eps=0.3, nu=2.5, seed=n + d)
+    th_o, w_o, outer_o = oracle.linear_regression(X, y, trace=True)
+    assert ops.linear_regression_check(n, d)
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    theta, w, info = ops.linear_regression(Xd, yd)
+    torch.cuda.synchronize()
+    info = info.cpu().numpy()
+    assert info[3] == 0 and info[0] == outer_o, (info, outer_o)
+    assert 1 <= info[1] <= 100 and info[1] <= info[2] <= 100 * info[0]
+    np.testing.assert_allclose(theta.cpu().numpy(), th_o, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(w.cpu().numpy(), w_o, rtol=1e-6, atol=1e-300)
+    # the numpy mirror takes the same launch (one pinned copy each way) and returns the same bits
+    th_m, w_m, outer_m = standard.linear_regression(X, y, return_info=True)
+    assert outer_m == outer_o and np.array_equal(th_m, theta.cpu().numpy()) and np.array_equal(w_m, w.cpu().numpy())
+    # maxiter is honoured on the device: one outer iteration, then zero
+    th1, w1, info1 = ops.linear_regression(Xd, yd, maxiter=1)
+    th0, w0, info0 = ops.linear_regression(Xd, yd, maxiter=0)
+    torch.cuda.synchronize()
+    assert int(info1[0]) == 1 and int(info0[0]) == 0
+    np.testing.assert_allclose(th0.cpu().numpy(), np.linalg.lstsq(X, y, rcond=None)[0], rtol=1e-9, atol=1e-11)
+    assert np.array_equal(w0.cpu().numpy(), np.ones(n))
+    assert dev_status(ops, dev) == 0
+
+
+def test_linear_regression_one_launch_limits_and_fallback(golden, gpu, oracle):
+    """Beyond n = 4096 or d = 31 the C entry refuses (RLVI_E_LIMIT) and the mirror takes the general path; a
+    rank-deficient design ends the launch with info[3] = 1 WITHOUT writing theta, and the mirror then returns
+    the minimum-norm solution of the general path (golden G5: the reference's lstsq result)."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib, standard
+    assert not ops.linear_regression_check(4097, 5) and not ops.linear_regression_check(100, 32)
+    X, y = synth.linreg_data(100, 32, seed=3)
+    with pytest.raises(_lib.RlviError):
+        ops.linear_regression(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev))
+    th_o, _, outer_o = oracle.linear_regression(X, y, trace=True)
+    th, _, outer = standard.linear_regression(X, y, return_info=True)
+    assert outer == outer_o
+    np.testing.assert_allclose(th, th_o, rtol=1e-8, atol=1e-10)
+    g = golden("g5_standard")
+    Xr, yr = g["linreg_rankdef/X"], g["linreg_rankdef/y"]
+    theta = torch.full((Xr.shape[1],), 7.0, dtype=torch.float64, device=dev)
+    _, _, info = ops.linear_regression(torch.from_numpy(Xr).to(dev), torch.from_numpy(yr).to(dev), theta=theta)
+    torch.cuda.synchronize()
+    assert int(info[3]) == 1 and bool((theta == 7.0).all())
+    ws = ops.workspace(dev)
+    np.testing.assert_allclose(standard.linear_regression(Xr, yr), g["linreg_rankdef/theta"], rtol=1e-7, atol=1e-9)
+    assert ws.status() & 8                    # RLVI_ST_SINGULAR: information, raised by the general path
+    ws.clear_status()
+    # non-finite data: the launch says "fallback", the general path returns NaN -- never a silent number
+    Xn = X[:, :5].copy()
+    Xn[3, 2] = np.nan
+    assert np.isnan(standard.linear_regression(Xn, y)).all()
+    ws.clear_status()
+
+
+@pytest.mark.parametrize("n,d", [(256, 60), (100, 3), (200, 561), (17, 130), (1000, 32), (4096, 20), (1, 7)])
+def test_online_sample_weight_in_one_launch_vs_oracle(n, d, gpu, oracle):
+    """rlvi_sample_weight_online_f64: X.w on the fp64 matrix cores -> -log sigmoid -> update_weights_rlvi in one
+    launch (online-learning/main.py:293-297) against the oracle on the same batch: residuals, iteration count,
+    sample weights; the first-batch form (log 2 everywhere) as well."""
+    torch, ops, dev = gpu
+    from rlvi_amd import online
+    Xl, wl, b = synth.logistic_data(n, d, seed=n + d)
+    l_o = oracle.logistic_nll(Xl, wl, b)
+    w_o, it_o = oracle.update_weights_rlvi(l_o, trace=True)
+    losses = torch.empty(n, dtype=torch.float64, device=dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    w, _, _ = ops.sample_weight_online(torch.from_numpy(Xl).to(dev), torch.from_numpy(wl).to(dev), b, losses=losses,
+                                       iters=iters)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), l_o, rtol=1e-11, atol=1e-14)
+    assert int(iters) == it_o
+    np.testing.assert_allclose(w.cpu().numpy(), w_o, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(online.rlvi_sample_weight(Xl, wl, b), w_o, rtol=1e-9, atol=1e-300)
+    w1, it1 = oracle.update_weights_rlvi(np.full(n, np.log(2.0)), trace=True)
+    np.testing.assert_allclose(online.rlvi_sample_weight(Xl), w1, rtol=1e-11)
+    wf, _, _ = ops.sample_weight_online(torch.from_numpy(Xl).to(dev), torch.from_numpy(wl).to(dev), b, first=True,
+                                        iters=iters)
+    torch.cuda.synchronize()
+    assert int(iters) == it1
+    np.testing.assert_allclose(wf.cpu().numpy(), w1, rtol=1e-11)
+
+
 def test_estimators_mean_pca_covariance_golden(golden, gpu):
     """the remaining standard-learning estimators on the GPU E-step."""
     from rlvi_amd import standard
@@ -1356,9 +1487,20 @@ def test_small_loss_baselines_bench_size_vs_oracle(gpu, oracle):
 def test_small_loss_baselines_train_loops(gpu):
     """train_usdnl / train_coteaching (reference signatures) on the synthetic digits with 40 %
     symmetric label noise: the loops run, the rate schedule is honoured, and small-loss selection
-    lifts the clean-label test accuracy far above the 60 % agreement with the noisy labels."""
+    lifts the clean-label test accuracy far above the 60 % agreement with the noisy labels.
+
+    Every batch of the usdnl loop is ALSO held against stock torch ops on the spot (per-sample CE, the kept
+    set, the selected mean and its gradient w.r.t. the logits): if the network is ever lost again, the failure
+    says whether the kernels agreed with torch up to that batch.  Round 3 saw one collapse (test accuracy 9 %)
+    of this loop at lr 0.1 inside a full suite run and none in a fresh process; the cause is the loop, not the
+    kernels: the SAME loop in stock torch on the CPU, same data / order / initialisation, under a 1e-6 relative
+    perturbation of the logits (the size of a different convolution algorithm's rounding, which is what a
+    process that has run other convolutions before picks) loses the network in 2 of 40 runs at lr 0.1 -- to
+    the very 9.1-9.2 % -- and spreads 94.6 ... 100 % otherwise, against 0 of 40 and 99.6 ... 100 % at lr 0.05
+    (profiles/r04_usdnl_lr_stability.txt, tools/lab/usdnl_lr_stability.py).  Hence lr 0.05."""
     torch, ops, dev = gpu
     import importlib
+    import torch.nn.functional as F
     from rlvi_amd import driver
     usdnl = importlib.import_module("rlvi_amd.methods.train_usdnl")
     cot = importlib.import_module("rlvi_amd.methods.train_coteaching")
@@ -1369,26 +1511,80 @@ def test_small_loss_baselines_train_loops(gpu):
     n_epoch = 12
     rate = np.ones(n_epoch) * 0.4
     rate[:4] = np.linspace(0, 0.4, 4)                         # main.py:179-180
+    checked = []
+
+    def checked_loss_fn(logits, labels, forget_rate, _orig=usdnl.loss_fn):
+        loss = _orig(logits, labels, forget_rate)
+        B = logits.shape[0]
+        k = int((1 - forget_rate) * B)
+        with torch.enable_grad():
+            zz = logits.detach().clone().requires_grad_(True)
+            ce = F.cross_entropy(zz, labels.long(), reduction='none')
+            keep = torch.argsort(ce.detach(), stable=True)[:k]
+            ref = ce[keep].mean()
+            (g_ref,) = torch.autograd.grad(ref, zz)
+            (g_dev,) = torch.autograd.grad(loss, logits, retain_graph=True)
+        where = f"epoch {len(checked) // 16} batch {len(checked) % 16}"
+        assert torch.isfinite(loss), where
+        assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (where, float(loss), float(ref))
+        assert float((g_dev - g_ref).abs().max()) <= 1e-6 + 1e-5 * float(g_ref.abs().max()), where
+        checked.append(float(loss))
+        return loss
+
     for which in ("usdnl", "coteaching"):
         # co-teaching's loss carries the reference's extra 1/num_remember (train_coteaching.py:35):
         # the same SGD step needs a learning rate ~num_remember times larger
-        # (0.05: at 0.1 one run in ten loses the network to a loss spike in epoch 3 -- every device result of
-        #  such a run still matches stock torch ops batch by batch, tools/lab/dbg_usdnl.py)
         lr = 0.05 if which == "usdnl" else 0.05 * 160
         m1 = driver.LeNet().to(dev)
         o1 = torch.optim.SGD(m1.parameters(), lr=lr, momentum=0.9)
         m2 = driver.LeNet().to(dev)
         o2 = torch.optim.SGD(m2.parameters(), lr=lr, momentum=0.9)
         loader = driver.IndexedLoader(x, y_noisy, 256, shuffle=True, seed=1)
-        for epoch in range(n_epoch):
-            if which == "usdnl":
-                acc = usdnl.train_usdnl(loader, epoch, m1, o1, rate)
-            else:
-                acc = cot.train_coteaching(loader, epoch, m1, o1, m2, o2, rate)
-            assert 0.0 <= acc <= 100.0
+        orig = usdnl.loss_fn
+        if which == "usdnl":
+            usdnl.loss_fn = checked_loss_fn
+        try:
+            for epoch in range(n_epoch):
+                if which == "usdnl":
+                    acc = usdnl.train_usdnl(loader, epoch, m1, o1, rate)
+                else:
+                    acc = cot.train_coteaching(loader, epoch, m1, o1, m2, o2, rate)
+                assert 0.0 <= acc <= 100.0
+        finally:
+            usdnl.loss_fn = orig
         test_acc = driver.evaluate(driver.IndexedLoader(xt, yt, 512, shuffle=False), m1, dev)
-        assert test_acc > 85.0, (which, test_acc)
+        assert test_acc > 85.0, (which, test_acc, "every batch matched stock torch" if which == "usdnl" else "")
+    assert len(checked) == n_epoch * 16
     assert ops.workspace(dev).status() == 0
+
+
+def test_calls_with_out_do_not_disturb_an_accumulate_sequence(gpu, oracle):
+    """ABI 3: a call WITH `out` (an evaluation batch, a small-loss selection, per_sample_ce) keeps its records
+    apart, so it may sit between the batches of an accumulate-mode epoch on the same workspace: the epoch's
+    scalars come out as without the interleaved calls, and the interleaved calls' own scalars are right."""
+    torch, ops, dev = gpu
+    B, C, N = 4096, 10, 8192
+    ws = ops.Workspace(dev, N, B)
+    d = [synth.mstep_inputs(B, C, N=N, seed=40 + i) for i in range(3)]
+    w = torch.from_numpy(d[0]["weights"]).to(dev)
+
+    def epoch(interleave):
+        res = torch.zeros(N, device=dev)
+        for i in range(3):
+            z, lab, idx = (torch.from_numpy(d[i][k]).to(dev) for k in ("logits", "labels", "idx"))
+            ops.mstep_fwd_bwd(z, lab, idx, w, res, ws=ws, accumulate=True)
+            if interleave:
+                ev = ops.evaluate_batch(z, lab, ws=ws)                         # with `out`
+                rows = ops.per_sample_ce(z, lab, ws=ws)                        # with `out`, 4096 x 10
+                ref_rows, hit = oracle.nll_rows(d[i]["logits"], d[i]["labels"])
+                np.testing.assert_allclose(rows.cpu().numpy(), ref_rows, rtol=1e-5, atol=1e-6)
+                assert abs(float(ev[0]) - float(ref_rows.astype(np.float64).mean())) <= 1e-5 * float(ref_rows.mean())
+                assert float(ev[3]) == float(hit.sum())
+        return ops.mstep_reduce(scale=1.0 / 3, ws=ws).cpu().numpy()
+
+    plain, mixed = epoch(False), epoch(True)
+    assert np.array_equal(plain, mixed)
+    assert not ws.pending_records() and ws.status() == 0
 
 
 def test_cpp_host_program_over_the_c_abi(gpu, tmp_path):
@@ -2112,7 +2308,7 @@ def test_cooperating_grids_follow_the_occupancy_answer(gpu, oracle):
             assert np.array_equal(w.cpu().numpy(), w_gpu) and int(kept) == int(mask_o.sum())
             assert ws.status() == 0
     finally:
-        _lib.check(L.rlvi_tune_set(b"RLVI_COOP_CAP", 0), "tune")
+        untune("RLVI_COOP_CAP")
 
 
 def test_threshold_guesses_from_the_previous_call(gpu, oracle):
