@@ -20,11 +20,13 @@ Inputs are resident in HBM before the timed region; 12 (logits, grad) buffer pai
 are captured into one hipGraph so the measurement is not host-launch-bound; timing is HIP events
 on the launch stream, bracketed by barrier + synchronize, MAX over ranks.
 
-Extra objects on the JSON line: `roofline` (the streaming M-step kernel, algorithmic bytes
-2*C*4+24 per sample against 8 TB/s), `cpu_baseline` (the CPU oracle timed on this box's host
-cores), `parts` (per-kernel times: M-step cold / warm / at 4x the rows, E-step, threshold +
-truncation, the in-batch E+M composition), `parity` (this run's outputs checked against the
-oracle: loss, gradient, pi, iteration count, selection mask).
+Extra objects on the JSON line: `roofline` (the streaming M-step kernel in the form train_rlvi runs -- no
+caller hint --, algorithmic bytes 2*C*4+24 per sample against 8 TB/s, next to a flat nontemporal copy of the
+same bytes in the same rotation and graph: `copy_same_bytes_us`, `frac_of_copy`), `cpu_baseline` (the CPU
+oracle timed on this box's host cores), `parts` (per-kernel times: M-step default / hinted / warm / at 4x the
+rows, E-step warm / cold / on drifting data, threshold + truncation, the in-batch E+M; `parts.configs`: what
+each of BASELINE.json's five configs calls, at its own shape, with the oracle's CPU time beside it),
+`parity` (this run's outputs checked against the oracle: loss, gradient, pi, iteration count, selection mask).
 """
 import argparse
 import json
@@ -277,6 +279,154 @@ def epoch_legs(torch, dev, a):
     return out
 
 
+def config_legs(torch, np, dev, ops, timed_part, cpu_jobs, out4):
+    """What each of BASELINE.json's five configs calls on this path, at the config's OWN shape (cfg1 ..
+    cfg5), each leg a hipGraph of >= 50 calls: `gpu_us` per call.  `cpu_jobs[(cfg, key)] = callable`: the pinned
+    oracle on the same inputs, timed in the cpu_baseline leg (`cpu_us`).  The shapes are launches of a few
+    microseconds -- launch- and latency-bound, the model's forward / backward dominates a real step there --, so
+    these are times, not roofline fractions."""
+    import time as _time
+    from rlvi_amd import _lib, online, standard, synth
+    from oracle import rlvi_oracle as O            # (the CPU jobs only: never inside a timed GPU region)
+    L = _lib.load()
+    cfgs = {}
+
+    def host_call_us(fn, reps=40):
+        for _ in range(5):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = _time.perf_counter()
+            fn()
+            ts.append(_time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e6
+
+    # ---- cfg1: standard-learning linear regression, n = 1000, d = 20, 30 % outliers (rlvi.py:68-89), fp64:
+    # the whole estimator is one launch; `call_us` = standard.linear_regression(X, y) as a numpy caller sees it
+    # (pinned H2D of [X | y], the launch, pinned D2H, one host wait)
+    X, y = synth.linreg_data(1000, 20, eps=0.3, nu=2.5, seed=0)
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    th = torch.empty(20, dtype=torch.float64, device=dev)
+    wv = torch.empty(1000, dtype=torch.float64, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def cfg1_leg(i, ws):
+        ops.linear_regression(Xd, yd, theta=th, weights=wv, info=info, ws=ws)
+    g1 = timed_part(cfg1_leg) * 1e3
+    inf = info.cpu().numpy()
+    cfgs["cfg1"] = {"what": "linear_regression(X, y) n=1000 d=20 f64, the whole estimator in one launch "
+                            "(rlvi_linear_regression_f64)",
+                    "gpu_us": g1, "outer_iterations": int(inf[0]), "inner_iterations": int(inf[2]),
+                    "call_us": host_call_us(lambda: standard.linear_regression(X, y)),
+                    "call_note": "numpy in / numpy out: pinned H2D of [X|y] (168 KB) + launch + pinned D2H + one host wait"}
+    cpu_jobs[("cfg1", "cpu_us")] = lambda: O.linear_regression_c(X, y)
+
+    # ---- cfg2: online-learning mini-batch, 256 x 60 (main.py:291-299): X.w -> -log sigmoid -> update_weights_rlvi
+    Xl, wl, b = synth.logistic_data(256, 60)
+    Xld, wld = torch.from_numpy(Xl).to(dev), torch.from_numpy(wl).to(dev)
+    sw = torch.empty(256, dtype=torch.float64, device=dev)
+    it2 = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def cfg2_leg(i, ws):
+        ops.sample_weight_online(Xld, wld, b, out=sw, iters=it2)
+    g2 = timed_part(cfg2_leg) * 1e3
+    cfgs["cfg2"] = {"what": "sample_weight of one online mini-batch 256x60 f64: X.w (MFMA) -> NLL -> online E-step, "
+                            "one launch (rlvi_sample_weight_online_f64)",
+                    "gpu_us": g2, "estep_iterations": int(it2.item()),
+                    "call_us": host_call_us(lambda: online.rlvi_sample_weight(Xl, wl, b))}
+    cpu_jobs[("cfg2", "cpu_us")] = lambda: O.update_weights_rlvi(O.logistic_nll(Xl, wl, b))
+
+    # ---- cfg3 / cfg4 / cfg5: the per-batch M-step and the per-epoch end at the deep-learning configs' shapes
+    wsc = ops.Workspace(dev, 75750, 4096)
+    it_c = torch.zeros(1, dtype=torch.int32, device=dev)
+    thr_c = torch.zeros(1, dtype=torch.float32, device=dev)
+    walk = [0, 1, 2, 3, 4, 3, 2, 1]
+    for name, (Bc, Cc, Nc, bf16, kind, label) in {
+            "cfg3": (4096, 10, 54000, False, "bimodal", "MNIST-shaped: batch 4096, 10 classes, N = 54 000"),
+            "cfg4": (4096, 10, 45000, False, "bimodal", "CIFAR-10-shaped: 32 768 / 8 ranks = 4096 rows per GPU, "
+                                                         "10 classes, N = 45 000"),
+            "cfg5": (1024, 101, 75750, True, "zeros10", "Food-101-shaped: 8192 / 8 ranks = 1024 rows per GPU, "
+                                                        "101 classes, bf16 logits, N = 75 750 slots (10 % never "
+                                                        "visited: residual 0)")}.items():
+        d = synth.mstep_inputs(Bc, Cc, N=Nc, seed=3)
+        z = torch.from_numpy(d["logits"]).to(dev)
+        z_cpu = d["logits"]
+        if bf16:
+            z = z.to(torch.bfloat16)
+            z_cpu = z.float().cpu().numpy()                # the reference fed the bf16-rounded logits as fp32
+        lab, idx = torch.from_numpy(d["labels"]).to(dev), torch.from_numpy(d["idx"]).to(dev)
+        wts = torch.from_numpy(d["weights"]).to(dev)
+        res = torch.zeros(Nc, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(z)
+
+        def mstep_leg(i, _ws):
+            ops.mstep_fwd_bwd(z, lab, idx, wts, res, grad=grad, ws=wsc, accumulate=True)
+        entry = {"what": label, "mstep_rows": Bc, "classes": Cc, "n_samples": Nc,
+                 "dtype": "bf16" if bf16 else "f32", "mstep_gpu_us": timed_part(mstep_leg) * 1e3}
+        ops.mstep_reduce(ws=wsc)
+        w_host = d["weights"]
+
+        def cpu_mstep(z_cpu=z_cpu, d=d, w_host=w_host, Nc=Nc):
+            O.mstep(z_cpu, d["labels"], d["idx"], w_host, np.zeros(Nc, np.float32))
+        cpu_jobs[(name, "mstep_cpu_us")] = cpu_mstep
+        # the epoch end on residuals that move from call to call (a neighbour's trajectory as the guess), without
+        # and with the truncation of train_rlvi.py:100-103
+        base = synth.residual_vector(kind, Nc, seed=5)
+        rng = np.random.default_rng(13)
+        dr_np = [(base * np.float32(1.02 ** k) + np.float32(0.01) * rng.random(Nc).astype(np.float32) * (base > 0))
+                 .astype(np.float32) for k in range(5)]
+        dr = [torch.from_numpy(v).to(dev) for v in dr_np]
+        w_e = torch.ones(Nc, dtype=torch.float32, device=dev)
+
+        def end_leg(i, _ws, overfit=0):
+            _lib.check(L.rlvi_epoch_end_f32(ops._ptr(dr[walk[i % 8]]), ops._ptr(w_e), Nc, 1e-3, 40, overfit, 0.05,
+                                            ops._ptr(thr_c), 0, None, ops._ptr(it_c), wsc.ptr, ops._stream_ptr()),
+                       "rlvi_epoch_end_f32")
+
+        def end_trunc_leg(i, _ws):
+            end_leg(i, _ws, 1)
+        wsc.reset_warm()
+        entry["epoch_end_gpu_us"] = timed_part(end_leg) * 1e3
+        entry["estep_iterations"] = int(it_c.item())
+        thr_c.zero_()
+        entry["epoch_end_truncating_gpu_us"] = timed_part(end_trunc_leg) * 1e3
+
+        def cpu_end(v=dr_np[2], Nc=Nc):
+            O.update_sample_weights(v.copy(), np.ones(Nc, np.float32))
+
+        def cpu_end_trunc(v=dr_np[2], Nc=Nc):
+            w_t = np.ones(Nc, np.float32)
+            O.update_sample_weights(v.copy(), w_t)
+            O.truncate(w_t, O.false_negative_criterion(w_t))
+        cpu_jobs[(name, "epoch_end_cpu_us")] = cpu_end
+        cpu_jobs[(name, "epoch_end_truncating_cpu_us")] = cpu_end_trunc
+        if name == "cfg3":
+            # the in-batch (online-order) E+M at this shape: one launch (a row per thread) / the three-launch composition
+            pi_s = torch.ones(Bc, dtype=torch.float32, device=dev)
+            rows_s = torch.empty(Bc, dtype=torch.float32, device=dev)
+            g_s = torch.empty_like(z)
+
+            def fused_small(i, _ws):
+                ops.fused_em(z, lab, pi_s, ws=wsc, out=out4, grad=g_s, rows=rows_s, iters=it_c)
+            entry["in_batch_em_gpu_us"] = timed_part(fused_small) * 1e3
+            _lib.check(L.rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
+            entry["in_batch_em_3launch_gpu_us"] = timed_part(fused_small) * 1e3
+            L.rlvi_tune_unset(b"RLVI_FUSED_EM")
+
+            def cpu_v2(z_cpu=z_cpu, d=d, Bc=Bc):
+                l_b, _ = O.nll_rows(z_cpu, d["labels"])
+                pi_b = np.ones(Bc, np.float32)
+                O.update_sample_weights(l_b, pi_b)
+                O.mstep(z_cpu, d["labels"], np.arange(Bc), pi_b, np.zeros(Bc, np.float32))
+            cpu_jobs[(name, "in_batch_em_cpu_us")] = cpu_v2
+        cfgs[name] = entry
+    st = wsc.status()
+    if st:
+        cfgs["device_status"] = st
+        wsc.clear_status()
+    return cfgs
+
+
 def main():
     a = parse()
     # IPC handles of device memory (the peers' inboxes of the sharded E-step, RCCL's own buffers) need the
@@ -379,10 +529,9 @@ def main():
         else:
             ops.epoch_end(residuals, weights, batches=1, out=out, iters=iters, ws=ws)
 
-    # every block of the rotation streams from HBM (12 x 52 MB between two uses of a line): tell the M-step
-    # launcher so -- reads first, then writes (ops.hint_logits_from_hbm, mstep.hip); the single-buffer leg
-    # below (mstep_warm_us: the block stays in the Infinity Cache) runs without the hint
-    ops.hint_logits_from_hbm(True)
+    # The headline step runs the M-step in the form train_rlvi runs it: NO caller hint (round 3 timed the headline
+    # under ops.hint_logits_from_hbm, a mode the plug-in never uses).  The hinted form -- every block of the rotation
+    # does stream from HBM -- is timed beside it on a workspace of its own (parts.mstep_hinted_us).
     estep_mode = ["replicated" if use_dist else "single"]
     estep_note = ""
     status_log = []        # every non-zero device status seen after a leg: it stays in the JSON line
@@ -572,10 +721,26 @@ def main():
             ms_total = timed(step, K, W, use_graph)
     ms_step = ms_total / K
     value = (B * world) / (ms_step * 1e-3)
+    # which physical GPUs ran: the PCI bus id of every rank's device (the same id in every process whatever the
+    # visible-device masks made of the ordinals).  Ranks that share a device are a protocol check, never an
+    # N-GPU measurement: n_gpus is the number of DISTINCT devices and the line says not_measured.
+    import ctypes as _ct
+    from rlvi_amd import _lib as _lb
+    _buf = _ct.create_string_buffer(64)
+    my_bus = _buf.value.decode() if _lb.load().rlvi_device_pci_bus_id(_buf, 64) == 0 else f"unknown-{rank}"
+    devices = [my_bus]
+    if use_dist and dist.is_initialized() and world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_bus)
+    n_physical = len(set(devices))
+    if world > 1 and n_physical < world:
+        shared_note = f"{world} ranks on {n_physical} GPU(s) (protocol check, not a scaling measurement)"
+        not_measured = shared_note if not_measured is None else not_measured + "; " + shared_note
 
     result = {
         "metric": "RLVI samples/sec (fused E+M step)",
-        "value": value, "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": value, "unit": "samples/s", "n_gpus": n_physical, "n_ranks": world, "n_physical_gpus": n_physical,
+        "steps": K, "warmup": W,
         "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": a.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -586,9 +751,11 @@ def main():
                                 "; E-step sharded over the ranks (per-node totals through the peers' inboxes, "
                                 "no collective call)" if estep_mode[0] == "sharded" else
                                 "; residuals all-gathered, E-step replicated on every rank"),
-                   "rows_per_gpu": B, "classes": C, "n_samples": N,
+                   "rows_per_gpu": B, "classes": C, "n_samples": N, "devices": devices,
+                   **({"same_device": True} if (a.same_device and world > 1) else {}),
                    "launch": launch_mode.get("step", "eager"), "estep_dist": estep_mode[0],
-                   "mstep_logits": "hinted as streaming from HBM (ops.hint_logits_from_hbm: reads first, then writes)",
+                   "mstep_logits": "default form, no caller hint (what train_rlvi runs); the hinted form is "
+                                   "parts.mstep_hinted_us",
                    **({"estep_dist_note": estep_note} if estep_note else {}),
                    **({"estep_dist_setup_s": round(setup_s, 3)} if setup_s is not None else {})},
     }
@@ -601,43 +768,99 @@ def main():
 
     # per-kernel legs (same buffers, same rotation): the HBM-bound M-step kernel and the
     # latency-bound E-step, each timed alone with HIP events on the launch stream
-    ms_m = timed(mstep_only, K, W, use_graph) / K
-    ms_e = timed(estep_only, K, W, use_graph) / K
+    KP = max(K, 50)                                  # calls per graph of a part leg (the driver runs --steps 20)
+
+    def timed_part(fn, k=None, w=None, reps=3):
+        """A part leg: a graph of k >= 50 calls, replayed `reps` times (each replay timed as the headline is);
+        the median replay, per call, in ms."""
+        k = KP if k is None else k
+        w = max(W if w is None else w, 1)          # (at least one eager call before a capture: one-time set-up)
+        ts = sorted(timed(fn, k, w, use_graph) / k for _ in range(reps))
+        return ts[len(ts) // 2]
+
+    ms_m = timed_part(mstep_only)
+    ms_e = timed_part(estep_only)
     extra = {}
     if world == 1:
+        from rlvi_amd import _lib as _lc
+        Lc = _lc.load()
+        # the same launch under the caller's hint that the block streams from HBM (a workspace option: the
+        # timed hold of mstep.hip), on a workspace of its own
+        ws_hint = ops.Workspace(dev, N, B)
+        ops.hint_logits_from_hbm(ws_hint, True)
+
+        def mstep_hinted(i, _ws):
+            r = i % ROTATE
+            ops.mstep_fwd_bwd(logits[r], labels, idx_local, weights, residuals, inv_scale=inv_scale,
+                              grad=grads[r], ws=ws_hint, accumulate=True)
+        extra["mstep_default_us"] = ms_m * 1e3
+        extra["mstep_hinted_us"] = timed_part(mstep_hinted) * 1e3
+        ops.mstep_reduce(ws=ws_hint)
+        # a flat nontemporal 16-B/lane copy of the same bytes (logits block -> gradient block) in the same
+        # rotation and graph: the plainest kernel that moves what the M-step moves -- this box's own ceiling
+        def copy_only(i, _ws):
+            r = i % ROTATE
+            ops.stream_copy(grads[r], logits[r])
+        extra["copy_same_bytes_us"] = timed_part(copy_only) * 1e3
         # single buffer pair: the block stays in the Infinity Cache between launches
         def mstep_warm(i, ws):
             ops.mstep_fwd_bwd(logits[0], labels, idx_local, weights, residuals, inv_scale=inv_scale,
                               grad=grads[0], ws=ws, accumulate=True)
-        ops.hint_logits_from_hbm(False)
-        extra["mstep_warm_us"] = timed(mstep_warm, K, W, use_graph) / K * 1e3
-        ops.hint_logits_from_hbm(True)
+        extra["mstep_warm_us"] = timed_part(mstep_warm) * 1e3
+        ops.mstep_reduce(ws=ws)
+        # ---- E-step beyond the warm case (estep_us: the same vector every call, the last call's trajectory is
+        # the guess).  Drift: a different residual vector every call -- the bimodal NLLs scaled by 1.02^k plus
+        # noise, k walking 0..4..0 -- as between the epochs of a training run: the guess is a neighbour's, not
+        # this vector's.  Cold: no guess at all (workspace option cold_start), every call as the reference's loop
+        # starts it (train_rlvi.py:29).  Each on a workspace of its own.
+        rng_d = np.random.default_rng(11)
+        r_base = residuals.detach().cpu().numpy().copy()
+        drift_np = [(r_base * np.float32(1.02 ** k) + np.float32(0.01) * rng_d.random(N).astype(np.float32))
+                    .astype(np.float32) for k in range(5)]
+        walk = [0, 1, 2, 3, 4, 3, 2, 1]
+        drift = [torch.from_numpy(v).to(dev) for v in drift_np]
+        w_e = torch.ones(N, dtype=torch.float32, device=dev)
+        it_e = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_drift, ws_cold = ops.Workspace(dev, N, 0), ops.Workspace(dev, N, 0)
+        ws_cold.set_option("cold_start", 1)
+
+        def estep_drift(i, _ws):
+            ops.estep_deep(drift[walk[i % len(walk)]], w_e, iters=it_e, ws=ws_drift)
+
+        def estep_cold(i, _ws):
+            ops.estep_deep(drift[walk[i % len(walk)]], w_e, iters=it_e, ws=ws_cold)
+        extra["estep_drift_us"] = timed_part(estep_drift) * 1e3
+        extra["estep_cold_us"] = timed_part(estep_cold) * 1e3
+        extra["estep_cold_iters"] = int(it_e.item())
         # threshold + truncation over N samples (the epoch end once `overfit` is set; V4)
         thr_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         w_thr = weights.clone()
 
         def threshold_only(i, ws):
-            from rlvi_amd import _lib
-            _lib.check(_lib.load().rlvi_threshold_truncate_f32(ops._ptr(w_thr), N, 0.05, ops._ptr(thr_buf),
-                                                               None, None, ws.ptr, ops._stream_ptr()),
-                       "rlvi_threshold_truncate_f32")
-        extra["threshold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
+            _lc.check(Lc.rlvi_threshold_truncate_f32(ops._ptr(w_thr), N, 0.05, ops._ptr(thr_buf),
+                                                     None, None, ws.ptr, ops._stream_ptr()),
+                      "rlvi_threshold_truncate_f32")
+        extra["threshold_us"] = timed_part(threshold_only) * 1e3
         extra["threshold_n"] = N
         # the criterion alone (false_negative_criterion, :41-49) on the E-step's pi as it is: the truncating call
         # above re-runs on its own output, whose thousands of exact zeros are not what an epoch end sees
         w_pi = weights.clone()
 
         def criterion_only(i, ws):
-            from rlvi_amd import _lib
-            _lib.check(_lib.load().rlvi_fn_threshold_f32(ops._ptr(w_pi), N, 0.05, ops._ptr(thr_buf), ws.ptr,
-                                                         ops._stream_ptr()), "rlvi_fn_threshold_f32")
-        extra["criterion_us"] = timed(criterion_only, K, W, use_graph) / K * 1e3
+            _lc.check(Lc.rlvi_fn_threshold_f32(ops._ptr(w_pi), N, 0.05, ops._ptr(thr_buf), ws.ptr,
+                                               ops._stream_ptr()), "rlvi_fn_threshold_f32")
+        extra["criterion_us"] = timed_part(criterion_only) * 1e3
         # (the same vector every call: every guess from the previous call is right.  Without any guess:)
-        from rlvi_amd import _lib as _lt
-        _lt.check(_lt.load().rlvi_tune_set(b"RLVI_THR_WARM", 0), "tune")
-        extra["threshold_cold_us"] = timed(threshold_only, K, W, use_graph) / K * 1e3
-        extra["criterion_cold_us"] = timed(criterion_only, K, W, use_graph) / K * 1e3
-        _lt.check(_lt.load().rlvi_tune_set(b"RLVI_THR_WARM", 1), "tune")
+        def threshold_cold(i, _ws):
+            _lc.check(Lc.rlvi_threshold_truncate_f32(ops._ptr(w_thr), N, 0.05, ops._ptr(thr_buf),
+                                                     None, None, ws_cold.ptr, ops._stream_ptr()),
+                      "rlvi_threshold_truncate_f32")
+
+        def criterion_cold(i, _ws):
+            _lc.check(Lc.rlvi_fn_threshold_f32(ops._ptr(w_pi), N, 0.05, ops._ptr(thr_buf), ws_cold.ptr,
+                                               ops._stream_ptr()), "rlvi_fn_threshold_f32")
+        extra["threshold_cold_us"] = timed_part(threshold_cold) * 1e3
+        extra["criterion_cold_us"] = timed_part(criterion_cold) * 1e3
         # in-batch E+M (V2): NLL pass -> E-step on this batch -> weighted loss + gradient
         pi_b = torch.ones(B, dtype=torch.float32, device=dev)
         rows_b = torch.empty(B, dtype=torch.float32, device=dev)
@@ -646,32 +869,15 @@ def main():
         def fused_only(i, ws):
             r = i % ROTATE
             ops.fused_em(logits[r], labels, pi_b, ws=ws, out=out, grad=grads[r], rows=rows_b, iters=it_f)
-        fe_ms = timed(fused_only, K, W, use_graph) / K
+        fe_ms = timed_part(fused_only)
         extra["fused_em_us"] = fe_ms * 1e3
         extra["fused_em_iters"] = int(it_f.item())
         # (one launch, the block resident in LDS between the passes, when the shape allows: fused_em.hip;
         #  V2 = 2*C*s + 16 bytes per sample -- logits in, gradient out, label, pi out, loss row out)
         extra["fused_em_frac"] = (B * (2 * C * 4 + 16) / (fe_ms * 1e-3)) / HBM_PEAK
-        from rlvi_amd import _lib as _l
-        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
-        extra["fused_em_3launch_us"] = timed(fused_only, K, W, use_graph) / K * 1e3
-        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
-        # the same at the reference's own class count (cfg3 / cfg4: 4096 x 10): one launch, a row per thread
-        Bs, Cs = 4096, 10
-        g_s = torch.Generator(device="cpu").manual_seed(7)
-        z_s = (3.0 * torch.randn(Bs, Cs, generator=g_s)).to(dev)
-        y_s = torch.randint(0, Cs, (Bs,), generator=g_s).to(dev)
-        z_s[torch.arange(0, Bs, 2, device=dev), y_s[::2]] += 12.0
-        pi_s = torch.ones(Bs, dtype=torch.float32, device=dev)
-        rows_s = torch.empty(Bs, dtype=torch.float32, device=dev)
-        grad_s = torch.empty_like(z_s)
-
-        def fused_small(i, ws):
-            ops.fused_em(z_s, y_s, pi_s, ws=ws, out=out, grad=grad_s, rows=rows_s, iters=it_f)
-        extra["fused_em_4096x10_us"] = timed(fused_small, K, W, use_graph) / K * 1e3
-        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
-        extra["fused_em_4096x10_3launch_us"] = timed(fused_small, K, W, use_graph) / K * 1e3
-        _l.check(_l.load().rlvi_tune_set(b"RLVI_FUSED_EM", 1), "tune")
+        _lc.check(Lc.rlvi_tune_set(b"RLVI_FUSED_EM", 0), "tune")
+        extra["fused_em_3launch_us"] = timed_part(fused_only) * 1e3
+        Lc.rlvi_tune_unset(b"RLVI_FUSED_EM")
         # the M-step at 4x the rows (3 rotating pairs = 630 MB): the same kernel with the fixed
         # launch / ramp-up share of a 10-us launch amortised -- separates steady-state bandwidth
         # from ramp-up by measurement
@@ -691,11 +897,15 @@ def main():
                 ops.mstep_fwd_bwd(big[i % 3], lab4, idx4, w4, r4, inv_scale=1.0 / B4, grad=gbig[i % 3],
                                   ws=ws4, accumulate=True)
             k4 = max(K // 4, 20)
-            ms4 = timed(mstep_big, k4, 6, use_graph) / k4
+            ms4 = timed_part(mstep_big, k4, 6)
             extra["mstep_4x_rows"] = B4
             extra["mstep_4x_us"] = ms4 * 1e3
             extra["mstep_4x_frac"] = (B4 * (2 * C * 4 + 24) / (ms4 * 1e-3)) / HBM_PEAK
             del big, gbig
+        # ---- what each of BASELINE.json's five configs calls, at its own shape (gpu_us; the oracle's cpu_us is
+        # added in the cpu_baseline leg below)
+        cfg_cpu_jobs = {}
+        extra["configs"] = config_legs(torch, np, dev, ops, timed_part, cfg_cpu_jobs, out)
         if not a.no_epoch_legs:
             extra["epoch"] = epoch_legs(torch, dev, a)
     bytes_per_sample = 2 * C * 4 + 24
@@ -708,7 +918,8 @@ def main():
     if os.path.exists(tpath) and (B, C) == (65536, 100):
         traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
     result["roofline"] = {
-        "bound": "hbm", "kernel": "rlvi::mstep_wave_kernel<float,4,4,7,4,true>",
+        "bound": "hbm", "kernel": "rlvi::mstep_wave_kernel<float,4,4,7,16,true>",
+        "form": "default: 16-wave workgroups, barrier behind the issue of the tile loads (no caller hint)",
         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": achieved / HBM_PEAK, "traffic": traffic,
         "traffic_unit": "bytes per launch (profiles/mstep_traffic.json)",
@@ -716,6 +927,12 @@ def main():
         "bytes_per_sample": bytes_per_sample, "us_per_launch": ms_m * 1e3,
         "step_frac": (B * bytes_per_sample / (ms_step * 1e-3)) / HBM_PEAK,
     }
+    if "copy_same_bytes_us" in extra:
+        # the flat copy moves 2 * C * 4 bytes per sample, the M-step 24 more (label, index, pi, residual)
+        result["roofline"]["copy_same_bytes_us"] = extra["copy_same_bytes_us"]
+        result["roofline"]["copy_frac_of_peak"] = (B * 2 * C * 4 / (extra["copy_same_bytes_us"] * 1e-6)) / HBM_PEAK
+        result["roofline"]["frac_of_copy"] = extra["copy_same_bytes_us"] / (ms_m * 1e3)
+        result["roofline"]["frac_hinted"] = (B * bytes_per_sample / (extra["mstep_hinted_us"] * 1e-6)) / HBM_PEAK
     result["parts"] = {"mstep_us": ms_m * 1e3, "estep_us": ms_e * 1e3,
                        "estep_iters": it_gpu, "estep_n": N,
                        "mstep_samples_per_s": B / (ms_m * 1e-3)}
@@ -800,6 +1017,20 @@ def main():
                          ("in_batch_em_v2_us", cpu_v2)):
             fn()
             parts_cpu[name] = median_time(fn, 9) * 1e6
+        # the configs' CPU times: the same oracle on the same inputs -- the faster of one thread and the calibrated
+        # thread count (a 4096 x 10 batch is over before 48 threads have started), median of 5
+        if "configs" in result["parts"]:
+            for (cfg, key), job in cfg_cpu_jobs.items():
+                best, cores = None, None
+                for t in sorted({1, best_t}):
+                    O.set_threads(t)
+                    job()
+                    v = median_time(job, 5) * 1e6
+                    if best is None or v < best:
+                        best, cores = v, t
+                result["parts"]["configs"][cfg][key] = round(best, 1)
+                result["parts"]["configs"][cfg][key.replace("_us", "_cores")] = cores
+            O.set_threads(best_t)
         result["cpu_baseline"] = {
             "value": B / med, "unit": "samples/s", "cores": best_t, "kind": "port",
             "sample": f"median of {len(ts)} full steps (M-step fwd+bwd + E-step) of the same {B}x{C} workload "

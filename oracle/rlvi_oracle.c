@@ -369,3 +369,93 @@ void rlvi_oracle_logistic_nll_f64(const double *X, const double *wv, double b,
         losses[i] = p >= 0.0 ? log1p(exp(-p)) : -p + log1p(exp(p));
     }
 }
+
+/* ------------------------------------------------------------------------- *
+ * a11: the whole estimator  linear_regression(X, y, maxiter=100, tol=1e-3)   (fp64)
+ *   standard-learning/rlvi.py:69-71  weights = 1; theta = lstsq(diag(sqrt(w)) X, diag(sqrt(w)) y)
+ *   rlvi.py:72-74                    residuals, sigma2, losses (rlvi_oracle_linreg_losses_f64)
+ *   rlvi.py:76-87                    repeat: weights = update_weights(losses) (tol 1e-3, maxiter 100: :8-20);
+ *                                    theta_prev = theta; theta = lstsq(...); losses; stop when
+ *                                    ||theta - prev|| / ||prev|| <= tol
+ * The reference's least-squares solve is scipy.linalg.lstsq (LAPACK gelsd, third party) on the sqrt(w)-scaled
+ * rows; here the same least-squares problem is solved by Householder QR of the scaled rows (no normal
+ * equations: the conditioning of the reference's solve).  Full column rank only -- a rank-deficient design
+ * (gelsd: minimum-norm solution) returns -1 and is left to the numpy restatement in rlvi_oracle.py.
+ * Pinned by tests/golden/g5_standard.npz (theta, final weights, outer-iteration count of the reference).
+ * Returns the number of outer iterations; inner_total (may be NULL) receives the E-step iterations in all.
+ * ------------------------------------------------------------------------- */
+static int oracle_wls_qr(const double *X, const double *y, const double *w, int64_t n, int64_t d,
+                         double *A, double *b, double *theta) {
+    /* A = diag(sqrt(w)) X (n x d, row-major), b = sqrt(w) y */
+    for (int64_t i = 0; i < n; ++i) {
+        const double s = sqrt(w[i]);
+        for (int64_t j = 0; j < d; ++j) A[i * d + j] = s * X[i * d + j];
+        b[i] = s * y[i];
+    }
+    double amax = 0.0;
+    for (int64_t k = 0; k < d; ++k) {
+        double nrm2 = 0.0;
+        for (int64_t i = k; i < n; ++i) nrm2 += A[i * d + k] * A[i * d + k];
+        const double nrm = sqrt(nrm2);
+        if (k == 0 || nrm > amax) amax = nrm > amax ? nrm : amax;
+        if (!(nrm > amax * (double)d * 64.0 * 2.220446049250313e-16)) return -1;     /* rank-deficient / not finite */
+        const double alpha = A[k * d + k] > 0.0 ? -nrm : nrm;
+        /* v = x - alpha e_k (stored in place), H = I - 2 v v^T / (v^T v) */
+        const double vkk = A[k * d + k] - alpha;
+        double vtv = vkk * vkk;
+        for (int64_t i = k + 1; i < n; ++i) vtv += A[i * d + k] * A[i * d + k];
+        A[k * d + k] = vkk;
+        for (int64_t j = k + 1; j < d; ++j) {
+            double dot = 0.0;
+            for (int64_t i = k; i < n; ++i) dot += A[i * d + k] * A[i * d + j];
+            const double f = 2.0 * dot / vtv;
+            for (int64_t i = k; i < n; ++i) A[i * d + j] -= f * A[i * d + k];
+        }
+        {
+            double dot = 0.0;
+            for (int64_t i = k; i < n; ++i) dot += A[i * d + k] * b[i];
+            const double f = 2.0 * dot / vtv;
+            for (int64_t i = k; i < n; ++i) b[i] -= f * A[i * d + k];
+        }
+        A[k * d + k] = alpha;                 /* R's diagonal; the rows below hold v and are not read again */
+    }
+    for (int64_t k = d - 1; k >= 0; --k) {    /* R theta = (Q^T b)[0 .. d) */
+        double s = b[k];
+        for (int64_t j = k + 1; j < d; ++j) s -= A[k * d + j] * theta[j];
+        theta[k] = s / A[k * d + k];
+    }
+    return 0;
+}
+
+int rlvi_oracle_linear_regression_f64(const double *X, const double *y, int64_t n, int64_t d, int maxiter,
+                                      double tol, double *theta, double *w, int *inner_total) {
+    double *A = (double *)malloc((size_t)n * (size_t)d * sizeof(double));
+    double *b = (double *)malloc((size_t)n * sizeof(double));
+    double *losses = (double *)malloc((size_t)n * sizeof(double));
+    double *prev = (double *)malloc((size_t)d * sizeof(double));
+    double *wn = (double *)malloc((size_t)n * sizeof(double));
+    int outer = 0, inner = 0, rc = 0;
+    for (int64_t i = 0; i < n; ++i) w[i] = 1.0;
+    rc = oracle_wls_qr(X, y, w, n, d, A, b, theta);
+    if (rc == 0) {
+        rlvi_oracle_linreg_losses_f64(X, y, theta, w, n, d, losses);
+        for (int o = 0; o < maxiter; ++o) {
+            ++outer;
+            inner += rlvi_oracle_update_weights_f64(losses, n, 1e-3, 100, wn, NULL);
+            memcpy(w, wn, (size_t)n * sizeof(double));
+            memcpy(prev, theta, (size_t)d * sizeof(double));
+            rc = oracle_wls_qr(X, y, w, n, d, A, b, theta);
+            if (rc != 0) break;
+            rlvi_oracle_linreg_losses_f64(X, y, theta, w, n, d, losses);
+            double dn = 0.0, pn = 0.0;
+            for (int64_t j = 0; j < d; ++j) {
+                dn += (theta[j] - prev[j]) * (theta[j] - prev[j]);
+                pn += prev[j] * prev[j];
+            }
+            if (sqrt(dn) / sqrt(pn) <= tol) break;
+        }
+    }
+    if (inner_total) *inner_total = inner;
+    free(A); free(b); free(losses); free(prev); free(wn);
+    return rc != 0 ? -1 : outer;
+}

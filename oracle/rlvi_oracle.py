@@ -70,6 +70,9 @@ def lib():
         L.rlvi_oracle_linreg_losses_f64.restype = ctypes.c_double
         L.rlvi_oracle_linreg_losses_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _i64, _f64p]
         L.rlvi_oracle_logistic_nll_f64.argtypes = [_f64p, _f64p, ctypes.c_double, _i64, _i64, _f64p]
+        L.rlvi_oracle_linear_regression_f64.restype = ctypes.c_int
+        L.rlvi_oracle_linear_regression_f64.argtypes = [_f64p, _f64p, _i64, _i64, ctypes.c_int, ctypes.c_double,
+                                                        _f64p, _f64p, ctypes.POINTER(ctypes.c_int)]
         _lib = L
     return _lib
 
@@ -287,6 +290,23 @@ def linear_regression(X, y, maxiter=100, tol=1e-3, trace=False):
     if trace:
         return theta, w, outer
     return theta
+
+
+def linear_regression_c(X, y, maxiter=100, tol=1e-3):
+    """a11 as ONE C call (rlvi_oracle.c: Householder QR of the sqrt(w)-scaled rows in place of scipy's lstsq,
+    full column rank only) -> (theta, w, outer, inner_total).  What bench.py times as cfg1's CPU baseline;
+    pinned to the same golden G5 as `linear_regression` above.  Raises on a rank-deficient design."""
+    X = _c(X, np.float64)
+    y = _c(y, np.float64)
+    n, d = X.shape
+    theta = np.empty(d, np.float64)
+    w = np.empty(n, np.float64)
+    inner = ctypes.c_int(0)
+    outer = lib().rlvi_oracle_linear_regression_f64(_p(X, _f64p), _p(y, _f64p), n, d, int(maxiter), float(tol),
+                                                    _p(theta, _f64p), _p(w, _f64p), ctypes.byref(inner))
+    if outer < 0:
+        raise np.linalg.LinAlgError("rank-deficient design: use linear_regression (scipy lstsq, minimum norm)")
+    return theta, w, outer, inner.value
 
 
 # ---- estimators of SURVEY 8(f)-2, restated around the same E-step -------------------------

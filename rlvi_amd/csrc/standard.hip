@@ -8,14 +8,14 @@
 // theta stops moving (rlvi.py:85-87) -- at n = 1000, d = 20 three outer iterations, 135 inner ones and four
 // solves of a 20 x 20 system: 40 kflop per product, nothing a launch per step or a host decision per outer
 // iteration could ever amortise (round 3: six launches + three torch ops + one host sync per outer iteration,
-// 0.62 ms per call).  Here the whole estimator is one persistent workgroup of eight waves:
-//   * the samples live in registers (n <= 4096: up to eight per thread) and in two LDS vectors (weights, squared
+// 0.62 ms per call).  Here the whole estimator is one persistent workgroup of four waves (one per SIMD):
+//   * the samples live in registers (n <= 4096: up to sixteen per thread) and in two LDS vectors (weights, squared
 //     residuals); every reduction of the fixed point is a wave butterfly + ONE workgroup barrier (partials in
 //     parity-buffered LDS slots, summed in wave order by everybody: all threads take the same stop decision);
 //   * the weighted Gram matrix [X | y]^T W [X | y] -- THE dense contraction of the path -- runs on the fp64 matrix
-//     cores (v_mfma_f64_16x16x4_f64), the 4-row k-panels of [X | y] staying in registers across the outer
-//     iterations when n <= 1024 (the weights change, the design does not); X.theta likewise (16 rows per wave
-//     and instruction, k over the columns);
+//     cores (v_mfma_f64_16x16x4_f64), sixteen 4-row k-panels of [X | y] per wave and trip with all their loads in
+//     flight together (the design stays in the L2); X.theta likewise (16 rows per wave and instruction, k over
+//     the columns);
 //   * the (d+1) x (d+1) system is factored (L D L^T) and solved by wave 0 with a row per lane in registers and
 //     v_readlane broadcasts -- no LDS round trip and no barrier per pivot;
 //   * the stop test ||theta - prev|| / ||prev|| <= tol is evaluated by every wave from LDS: no host in the loop,
@@ -31,11 +31,15 @@ namespace rlvi {
 
 typedef double sd4_t __attribute__((ext_vector_type(4)));
 
-constexpr int SL_THREADS = 512;
-constexpr int SL_NW = SL_THREADS / WAVE;          // 8 waves: two per SIMD, 256 registers each
+// (four waves, one per SIMD: a reduction of the fixed point costs every WAVE ~80 instructions whatever it holds, and
+//  two waves on a SIMD take turns at its issue slots -- eight waves with two samples per thread measured 0.79 us per
+//  inner iteration)
+constexpr int SL_THREADS = 256;
+constexpr int SL_NW = SL_THREADS / WAVE;
 constexpr int SL_DP = 32;                         // [X | y] padded to two 16-column blocks: d <= 31
+constexpr int SL_RU = 4;                           // 16-row blocks of the residual pass in flight per wave and trip
 constexpr int SL_GU = 16;                          // 4-row k-panels of the Gram loop in flight per wave and trip
-constexpr int SL_MAXN = 4096;                     // samples the one-workgroup form takes (8 per thread)
+constexpr int SL_MAXN = 4096;                     // samples the one-workgroup form takes (16 per thread)
 constexpr int SL_GPITCH = SL_DP + 1;
 
 // 1 / x to working precision: v_rcp_f64 + two Newton steps (the factorisation's pivots; not correctly rounded,
@@ -46,6 +50,9 @@ __device__ __forceinline__ double sl_rcp(double x) {
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
 }
+// the value is needed HERE, whatever later selects do with it: keeps the compiler from sinking a load into the
+// branch of the select that consumes it (a load under a branch is waited for before the next one is issued)
+__device__ __forceinline__ void sl_keep(double &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ double sl_readlane(double v, int l) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xFFFFFFFFll), l);
@@ -70,7 +77,19 @@ __device__ __forceinline__ void sl_block_sum2(double &a, double &b, double *slot
     parity ^= 1;
 }
 
+// lab build (-DRLVI_STAMPS=1, tools/build_variants.py): thread 0 leaves 100 MHz wall-clock stamps of the phases in
+// the workspace scratch (tools/lab/linreg_phases.py prints them); compiled out of the product library
+#if RLVI_STAMPS
+#define SL_STAMP() do { if (threadIdx.x == 0 && sh.nst < 120) sh.dbg[sh.nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SL_STAMP() do { } while (0)
+#endif
+
 struct SlShared {
+#if RLVI_STAMPS
+    mutable unsigned long long *dbg;
+    mutable int nst;
+#endif
     double *wsh;        // [npad]  weights (pads 0)
     double *rsh;        // [npad]  squared residuals
     double *red;        // [SL_NW][3][256]  Gram partials of the waves
@@ -94,20 +113,46 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
     const int steps = (n + 3) / 4;
     // SL_GU k-panels (4 rows each) per trip, all their loads in flight together: the design comes from the L2
     // (160 KB at n = 1000, d = 20) and a trip's registers are free again before the factorisation needs its own.
-    // (Keeping the panels in registers across the outer iterations was built first: 128 registers that are live
-    //  through the factorisation on wave 0 -- spills -- to save ~1 us per solve.)
+    // One CU streams from the L2 at ~45 GB/s (its outstanding misses x the L2's latency), so a pass over the
+    // design is microseconds whatever the loop looks like: in-kernel stamps (tools/lab/linreg_phases.py) put this
+    // pass and the residual pass at the top of the launch's time beside the E-step's serial reductions.
     for (int s0 = wave; s0 < steps; s0 += SL_GU * SL_NW) {
         double x0[SL_GU], x1[SL_GU], w[SL_GU];
+        int xrow0[SL_GU];
 #pragma unroll
         for (int u = 0; u < SL_GU; ++u) {
             const int s = s0 + u * SL_NW;
             const int row = 4 * s + kk;
             const bool ok = s < steps && row < n;
-            const int c0 = i, c1 = 16 + i;
-            const double *xp = X + (size_t)(ok ? row : 0) * d;
-            x0[u] = ok ? (c0 < d ? xp[c0] : (c0 == d ? y[row] : 0.0)) : 0.0;
-            x1[u] = (DP > 16 && ok) ? (c1 < d ? xp[c1] : (c1 == d ? y[row] : 0.0)) : 0.0;
-            w[u] = ok ? sh.wsh[row] : 0.0;
+            const int rr = ok ? row : 0;
+            // every lane that HAS a column (its column of X, or y) loads from an always valid row, and the value
+            // is selected afterwards; the lanes without one (5 of a second block's 16 carry data at d = 20) ask for
+            // nothing.  One branch around ALL loads of the trip: a load under a branch of its own is waited for
+            // before the next one is issued (the first version of this loop: 64 dependent round trips per trip)
+            xrow0[u] = rr;
+            w[u] = sh.wsh[rr];
+            x0[u] = 0.0;
+            x1[u] = 0.0;
+        }
+        if (i <= d) {
+#pragma unroll
+            for (int u = 0; u < SL_GU; ++u) x0[u] = *(i < d ? X + (size_t)xrow0[u] * d + i : y + xrow0[u]);
+        }
+        if (DP > 16 && 16 + i <= d) {
+#pragma unroll
+            for (int u = 0; u < SL_GU; ++u) x1[u] = *(16 + i < d ? X + (size_t)xrow0[u] * d + 16 + i : y + xrow0[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // every load of the trip is out before the first value is used
+#pragma unroll
+        for (int u = 0; u < SL_GU; ++u) {
+            // (the predicates again, from the indices: kept across the barrier they are 48 lane masks)
+            const int s = s0 + u * SL_NW;
+            const bool ok = s < steps && 4 * s + kk < n;
+            sl_keep(x0[u]);
+            if (DP > 16) sl_keep(x1[u]);
+            x0[u] = (ok && i <= d) ? x0[u] : 0.0;
+            x1[u] = (DP > 16 && ok && 16 + i <= d) ? x1[u] : 0.0;
+            w[u] = ok ? w[u] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < SL_GU; ++u) {
@@ -119,6 +164,7 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
             }
         }
     }
+    SL_STAMP();   // gram loop done
     // the waves' partial blocks -> LDS; element e of a block = (result r, lane): row (lane >> 4) + 4 r, column lane & 15
     constexpr int NBLK = DP > 16 ? 3 : 1;
     double *my = sh.red + (size_t)wave * 3 * 256;
@@ -147,6 +193,7 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
                                                        //  block is another rounding of the same sum)
     }
     __syncthreads();
+    SL_STAMP();   // block sums done
     // ---- wave 0: G = L D L^T, row t of the lower triangle in lane t's registers
     if (wave == 0) {
         int t = lane & (SL_DP - 1);
@@ -196,6 +243,7 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
         if (lane == 0) sh.flag[0] = bad ? 1 : 0;
     }
     __syncthreads();
+    SL_STAMP();   // solved
     return sh.flag[0] == 0;
 }
 
@@ -206,28 +254,46 @@ __device__ __forceinline__ double sl_residuals(const SlShared &sh, const double 
     const int i = lane & 15, kk = lane >> 4;
     double num = 0.0, den = 0.0;
     const int blocks = (n + 15) / 16;
-    for (int rb = wave; rb < blocks; rb += SL_NW) {
-        // X[16 rb .. +15] . theta on the matrix cores: A = a 16 x 4 panel of X, B = the 4 matching entries of
-        // theta in every column; lane l's results are rows (l >> 4) + 4 r, all columns alike
-        const int row = 16 * rb + i;
-        const bool rok = row < n;
-        const double *xrow = X + (size_t)(rok ? row : 0) * d;
-        sd4_t acc = {0.0, 0.0, 0.0, 0.0};
-        double a[8], bv[8];
+    // X[16 rb .. +15] . theta on the matrix cores: A = a 16 x 4 panel of X, B = the 4 matching entries of theta in
+    // every column; lane l's results are rows (l >> 4) + 4 r, all columns alike.  SL_RU row blocks per wave and
+    // trip, all their loads in flight together (one block per trip was one L2 round trip per 16 rows: 11 us per
+    // pass at n = 1000).
+    double bv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                                // d <= 31: eight 4-column panels at most
-            const int k = 4 * u + kk;
-            a[u] = (rok && k < d) ? xrow[k] : 0.0;
-            bv[u] = k < d ? sh.th[k] : 0.0;
+    for (int u = 0; u < 8; ++u) {                                    // d <= 31: eight 4-column panels at most
+        const int k = 4 * u + kk;
+        const double tv = sh.th[k < d ? k : 0];
+        bv[u] = k < d ? tv : 0.0;
+    }
+    for (int rb0 = wave; rb0 < blocks; rb0 += SL_RU * SL_NW) {
+        double a[SL_RU][8], yv[SL_RU];
+#pragma unroll
+        for (int q = 0; q < SL_RU; ++q) {
+            const int rb = rb0 + q * SL_NW;
+            const int row = 16 * rb + i;
+            const double *xrow = X + (size_t)(row < n ? row : 0) * d;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[q][u] = xrow[(4 * u + kk) < d ? 4 * u + kk : 0];      // (branch-free)
+            const int r = 16 * rb + kk + 4 * (i & 3);
+            yv[q] = y[r < n ? r : 0];
         }
+        __builtin_amdgcn_sched_barrier(0);        // every load of the trip is out before the first value is used
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (4 * u < d) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv[u], acc, 0, 0, 0);
-        if (i < 4) {
+        for (int q = 0; q < SL_RU; ++q) {
+            const int rb = rb0 + q * SL_NW;
+            const bool rok = 16 * rb + i < n;
+            sd4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sl_keep(a[q][u]);
+                const double av = (rok && 4 * u + kk < d) ? a[q][u] : 0.0;
+                if (4 * u < d) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc, 0, 0, 0);
+            }
+            sl_keep(yv[q]);
             const int r = 16 * rb + kk + 4 * i;
-            if (r < n) {
+            if (i < 4 && r < n) {
                 const double p = i == 0 ? acc[0] : i == 1 ? acc[1] : i == 2 ? acc[2] : acc[3];
-                const double e = y[r] - p, rr = e * e;
+                const double e = yv[q] - p, rr = e * e;
                 const double w = sh.wsh[r];
                 sh.rsh[r] = rr;
                 num = __builtin_fma(w, rr, num);
@@ -236,6 +302,7 @@ __device__ __forceinline__ double sl_residuals(const SlShared &sh, const double 
         }
     }
     sl_block_sum2(num, den, sh.slots, parity);      // (its barrier also publishes rsh)
+    SL_STAMP();   // residuals done
     return num / den;
 }
 
@@ -243,9 +310,15 @@ template <int E, int DP>
 __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
     const double *__restrict__ X, const double *__restrict__ y, int n, int d, int npad, int maxiter, double tol,
     double etol, int emaxiter, double *__restrict__ theta_out, double *__restrict__ w_out,
-    int32_t *__restrict__ info) {
+    int32_t *__restrict__ info, unsigned long long *__restrict__ dbg) {
     extern __shared__ double sm[];
     SlShared sh;
+#if RLVI_STAMPS
+    sh.dbg = dbg;
+    sh.nst = 0;
+#else
+    (void)dbg;
+#endif
     sh.wsh = sm;
     sh.rsh = sh.wsh + npad;
     sh.red = sh.rsh + npad;
@@ -267,6 +340,7 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
     bool ok = true;
     const double invn = 1.0 / (double)n;
     for (;;) {
+        SL_STAMP();   // outer iteration starts
         // theta from the current weights (rlvi.py:70-71 the first time, :79-80 afterwards), then the residuals
         // and sigma2 (:72-73, :81-82)
         ok = sl_wls<DP>(sh, X, y, n, d);
@@ -280,7 +354,7 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
         }
         if (outer >= maxiter) break;
         ++outer;
-        // ---- update_weights(losses) (rlvi.py:8-20, called at :77) on this thread's samples tid + 512 j
+        // ---- update_weights(losses) (rlvi.py:8-20, called at :77) on this thread's samples tid + 256 j
         double e[E], w[E];
         const double hs = 0.5 / sigma2;
 #pragma unroll
@@ -293,6 +367,7 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
         double ratio;
         { const double eps = 1.0 - 0.95; ratio = eps / (1.0 - eps); }
         int it = 0;
+        SL_STAMP();   // exp done
         while (it < emaxiter) {
             double sse = 0.0, sum = 0.0;
 #pragma unroll
@@ -311,6 +386,7 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
             const double eps = 1.0 - sum * invn;                   // rlvi.py:13-14
             ratio = eps / (1.0 - eps);
         }
+        SL_STAMP();   // E-step done
         inner_last = it;
         inner_all += it;
 #pragma unroll
@@ -361,9 +437,12 @@ __global__ __launch_bounds__(SL_THREADS) void online_weight_kernel(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + kk;
-                    a[u] = rok ? xrow[k] : 0.0;
+                    a[u] = xrow[k];                                 // (row 0 for rows past n: valid, selected away)
                     bv[u] = wv[k];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sl_keep(a[u]); a[u] = rok ? a[u] : 0.0; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv[u], acc, 0, 0, 0);
             }
@@ -372,8 +451,17 @@ __global__ __launch_bounds__(SL_THREADS) void online_weight_kernel(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + kk;
-                    a[u] = (rok && k < d) ? xrow[k] : 0.0;
-                    bv[u] = k < d ? wv[k] : 0.0;
+                    a[u] = xrow[k < d ? k : 0];                     // (branch-free loads, selected below)
+                    bv[u] = wv[k < d ? k : 0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 4 * u + kk;
+                    sl_keep(a[u]);
+                    sl_keep(bv[u]);
+                    a[u] = (rok && k < d) ? a[u] : 0.0;
+                    bv[u] = k < d ? bv[u] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -478,18 +566,19 @@ extern "C" int rlvi_linear_regression_f64(const double *X, const double *y, int6
             attr_dev = cur;
         }
         return launch(kern, dim3(1), dim3(SL_THREADS), lds, st, X, y, (int)n, (int)d, npad_x, maxiter, tol,
-                      estep_tol, estep_maxiter, theta, weights, info);
+                      estep_tol, estep_maxiter, theta, weights, info,
+                      reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF));
     };
-    // (samples per thread: two up to n = 1024, eight beyond; the system padded to 16, 24 or 32 rows)
+    // (samples per thread: four up to n = 1024, sixteen beyond; the system padded to 16, 24 or 32 rows)
     const int dp = d < 16 ? 16 : (d < 24 ? 24 : 32);
-    if (n <= 2 * SL_THREADS) {
-        if (dp == 16) return go(linreg_rlvi_kernel<2, 16>);
-        if (dp == 24) return go(linreg_rlvi_kernel<2, 24>);
-        return go(linreg_rlvi_kernel<2, 32>);
+    if (n <= 4 * SL_THREADS) {
+        if (dp == 16) return go(linreg_rlvi_kernel<4, 16>);
+        if (dp == 24) return go(linreg_rlvi_kernel<4, 24>);
+        return go(linreg_rlvi_kernel<4, 32>);
     }
-    if (dp == 16) return go(linreg_rlvi_kernel<8, 16>);
-    if (dp == 24) return go(linreg_rlvi_kernel<8, 24>);
-    return go(linreg_rlvi_kernel<8, 32>);
+    if (dp == 16) return go(linreg_rlvi_kernel<16, 16>);
+    if (dp == 24) return go(linreg_rlvi_kernel<16, 24>);
+    return go(linreg_rlvi_kernel<16, 32>);
 }
 
 extern "C" int rlvi_sample_weight_online_f64(const double *X, const double *w, double b, int first, int64_t n,
@@ -507,6 +596,7 @@ extern "C" int rlvi_sample_weight_online_f64(const double *X, const double *w, d
     if (n <= SL_THREADS) RLVI_OW(1);
     if (n <= 2 * SL_THREADS) RLVI_OW(2);
     if (n <= 4 * SL_THREADS) RLVI_OW(4);
-    RLVI_OW(8);
+    if (n <= 8 * SL_THREADS) RLVI_OW(8);
+    RLVI_OW(16);
 #undef RLVI_OW
 }

@@ -1621,7 +1621,11 @@ def test_bench_two_ranks_on_one_gpu(mode, gpu):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["device_status"] == 0
+    # two ranks on ONE device are a protocol check: the record says so (n_gpus = distinct devices, by PCI bus id)
+    assert res["n_gpus"] == 1 and res["n_ranks"] == 2 and res["n_physical_gpus"] == 1 and res["config"]["same_device"]
+    assert "2 ranks on 1 GPU" in res["not_measured"]
+    assert len(res["config"]["devices"]) == 2 and len(set(res["config"]["devices"])) == 1
+    assert res["scaling"] == "weak" and res["device_status"] == 0
     assert res["config"]["n_samples"] == 65536 and res["parts"]["estep_iters"] >= 1
     assert res["config"]["estep_dist"] == ("sharded" if mode == "auto" else "replicated"), res["config"]
     if mode == "auto":
@@ -1646,7 +1650,8 @@ def _run_bench(args, timeout=400, env_extra=None):
 def test_bench_spawns_its_own_ranks(gpu):
     """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's command): the parent starts
     two fresh ranks before it touches the GPU and passes rank 0's one JSON line through; here the ranks
-    share cuda:0 (gloo for the host-side collectives).  n_gpus says 2, the sharded E-step passed its
+    share cuda:0 (gloo for the host-side collectives).  The record says which devices ran (config.devices: the
+    PCI bus id of every rank) and, the two being one, n_gpus 1 / not_measured; the sharded E-step passed its
     start-up self-check (each rank took half of the device's co-residency: RLVI_DEVICE_SHARERS), no
     device status in any leg."""
     p, recs = _run_bench(["--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6", "--warmup", "2",
@@ -1654,7 +1659,9 @@ def test_bench_spawns_its_own_ranks(gpu):
     assert p.returncode == 0, p.stderr[-2000:]
     assert len(recs) == 1
     res = recs[0]
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and "not_measured" not in res
+    assert res["n_gpus"] == 1 and res["n_ranks"] == 2 and res["scaling"] == "weak"
+    assert "2 ranks on 1 GPU" in res["not_measured"] and res["config"]["same_device"]
+    assert len(res["config"]["devices"]) == 2 and res["config"]["devices"][0] == res["config"]["devices"][1]
     assert res["device_status"] == 0 and "device_status_events" not in res
     assert res["config"]["estep_dist"] == "sharded" and res["config"]["launch"] == "hipGraph"
     assert res["config"]["n_samples"] == 65536 and res["config"]["estep_dist_setup_s"] < 30.0
@@ -1666,7 +1673,7 @@ def test_bench_strong_scaling_splits_the_same_batch(gpu):
                           "--scaling", "strong", "--no-cpu-baseline"])
     assert p.returncode == 0, p.stderr[-2000:]
     res = recs[0]
-    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["device_status"] == 0
+    assert res["n_ranks"] == 2 and res["n_gpus"] == 1 and res["scaling"] == "strong" and res["device_status"] == 0
     assert res["config"]["rows_per_gpu"] == 32768 and res["config"]["n_samples"] == 65536
     assert res["parts"]["estep_iters"] >= 1 and res["value"] > 0
 
@@ -1681,6 +1688,7 @@ def test_bench_with_fewer_devices_than_asked_says_so(gpu):
     assert p.returncode == 0, p.stderr[-2000:]
     res = recs[0]
     assert res["n_gpus"] == 1 and res["not_measured"] == "2 requested, 1 visible"
+    assert len(res["config"]["devices"]) == 1 and res["n_physical_gpus"] == 1
     assert res["parity"]["ok"] and res["device_status"] == 0
 
 
