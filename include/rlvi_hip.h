@@ -94,6 +94,9 @@ int rlvi_workspace_clear_status(void *ws, void *stream);
  *       reference's loop starts it, train_rlvi.py:29; the results never depend on the guesses, only the time does).
  * RLVI_E_SHAPE for an unknown name. */
 int rlvi_workspace_set_option(void *ws, const char *name, int value);
+/* Which form the last M-step launch on this workspace took (tests of the dispatch): 0 none yet, 1 register rows,
+ * 2 wave tiles in four-wave workgroups, 3 wave tiles in 16-wave workgroups; + 16 with a timed hold. */
+int rlvi_workspace_last_mstep_form(const void *ws);
 /* Forget the guesses earlier calls left for the next one (E-step trajectory and minimum, threshold key). */
 int rlvi_workspace_reset_warm(void *ws, void *stream);
 /* Byte offset (and size through *bytes) of a region of the workspace layout, for tools and tests: "records"
@@ -199,6 +202,7 @@ int rlvi_estep_sharded_f32(float *residuals, float *weights, int64_t n_local, in
  * bit-exact as on one device); *thr_inout and *kept_out (over ALL ranks) are identical on every rank,
  * the truncation and mask_gt cover this rank's n_local weights.  RLVI_E_LIMIT for n_local <= 1024;
  * a weight outside [0, 1] raises RLVI_ST_NOCONV (the one-device generic form cannot see the others). */
+int rlvi_threshold_sharded_check(int64_t n_local, int64_t n_all);   /* 0 / RLVI_E_LIMIT: would the call below launch? */
 int rlvi_threshold_truncate_sharded_f32(float *weights, int64_t n_local, int64_t n_all, float alpha,
                                         float *thr_inout, uint8_t *mask_gt, int64_t *kept_out,
                                         void *ws, void *stream);
@@ -247,13 +251,15 @@ int rlvi_select_smallest_f32(const float *loss, int64_t n, int64_t k, float *mas
 /* ---------------------------------------------------------------------------------------
  * In-batch fused E+M (online order, online-learning/main.py:296-299 applied to a logit block):
  * per-sample NLL -> E-step on THIS batch (deep variant, pi_in only feeds the first error)
- * -> weighted loss and gradient with the NEW pi.  Composition of a1, a7, a4, a5 -- as ONE launch
- * with the logit block resident in the chip's LDS between the two passes (fused_em.hip) for fp32
- * dense rows, 4 | C, 32 <= C <= 128, 16 | B, 16 129 <= B <= 65 536 on a 256-CU device (bit-identical
- * to the composition where the E-step slices coincide, a few ulp elsewhere), and with a row per thread
- * for fp32 dense rows of C <= 16 (the ten classes of MNIST / CIFAR-10), 64 <= B <= 65 536, or four
- * lanes per row for 4 | C, 16 < C <= 128, 64 <= B <= 16 384 (pi, loss rows and gradient within 1e-5
- * of the composition, same iteration count); three launches otherwise.
+ * -> weighted loss and gradient with the NEW pi.  Composition of a1, a7, a4, a5 -- as ONE launch for fp32 dense
+ * rows (fused_em.hip), tried in this order on a 256-CU device:
+ *   C <= 16 (the ten classes of MNIST / CIFAR-10), 64 <= B <= 65 536: a row per thread;
+ *   4 | C, 16 < C <= 128, 64 <= B <= 16 384: four lanes per row, the rows in registers;
+ *   4 | C, 32 <= C <= 128, 16 | B, 16 385 <= B <= 65 536 (and 16 129 <= B <= 16 384 when the form above is refused
+ *   for lack of co-resident workgroups): the logit block resident in the chip's LDS between the two passes --
+ *   bit-identical to the composition where the E-step slices coincide (B > 65 280), a few ulp elsewhere.
+ * The two register forms: pi, loss rows and gradient within 1e-5 of the composition, same iteration count.
+ * Everything else (bf16, 4 does not divide C > 16, more than 65 536 rows, strided rows): three launches.
  *   loss_rows [B] receives the min-shifted NLL, pi [B] the new posteriors (in/out).
  * ------------------------------------------------------------------------------------- */
 int rlvi_fused_em_f32(const float *logits, int64_t ld, const int64_t *labels, float *loss_rows,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "rlvi_workspace_clear_status": (_int, [_vp, _vp]),
     "rlvi_workspace_set_option": (_int, [_vp, ctypes.c_char_p, _int]),
     "rlvi_workspace_reset_warm": (_int, [_vp, _vp]),
+    "rlvi_workspace_last_mstep_form": (_int, [_vp]),
     "rlvi_workspace_region": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]),
     "rlvi_peer_inbox_bytes": (ctypes.c_size_t, []),
     "rlvi_peer_alloc": (_int, [ctypes.POINTER(ctypes.c_void_p)]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "rlvi_workspace_set_peers": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_void_p), _vp]),
     "rlvi_threshold_truncate_sharded_f32": (_int, [_vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "rlvi_estep_sharded_check": (_int, [_i64, _i64, _int, _int]),
+    "rlvi_threshold_sharded_check": (_int, [_i64, _i64]),
     "rlvi_estep_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _f32, _int, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_mstep_fwd_bwd_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                       _vp, _i64, _vp, _vp, _vp]),

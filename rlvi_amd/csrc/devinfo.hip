@@ -176,7 +176,7 @@ extern "C" int rlvi_tune_overrides(char *buf, int len) {
 // as opposed to the process-wide tuning knobs above)
 namespace rlvi {
 namespace {
-struct WsOptions { int v[WSOPT_COUNT]; bool set[WSOPT_COUNT]; };
+struct WsOptions { int v[WSOPT_COUNT]; bool set[WSOPT_COUNT]; int last_mstep; };
 std::unordered_map<const void *, WsOptions> g_wsopt;
 std::mutex g_wsopt_mu;
 }  // namespace
@@ -185,6 +185,10 @@ int ws_option(const void *ws, int which, int dflt) {
     std::lock_guard<std::mutex> lk(g_wsopt_mu);
     auto it = g_wsopt.find(ws);
     return (it != g_wsopt.end() && it->second.set[which]) ? it->second.v[which] : dflt;
+}
+void ws_note_mstep(const void *ws, int code) {
+    std::lock_guard<std::mutex> lk(g_wsopt_mu);
+    g_wsopt[ws].last_mstep = code;
 }
 void ws_options_forget(const void *ws) {
     std::lock_guard<std::mutex> lk(g_wsopt_mu);
@@ -203,6 +207,15 @@ extern "C" int rlvi_workspace_set_option(void *ws, const char *name, int value) 
     o.v[which] = value;
     o.set[which] = true;
     return 0;
+}
+
+// Which form the LAST M-step launch on this workspace took (for tests of the dispatch): 0 = none yet, 1 = register
+// rows, 2 = wave tiles in four-wave workgroups, 3 = wave tiles in 16-wave workgroups (barrier behind the load
+// issue); + 16 when the launch carried a timed hold (the caller's "logits_from_hbm" hint or the lab knob).
+extern "C" int rlvi_workspace_last_mstep_form(const void *ws) {
+    std::lock_guard<std::mutex> lk(rlvi::g_wsopt_mu);
+    auto it = rlvi::g_wsopt.find(ws);
+    return it == rlvi::g_wsopt.end() ? 0 : it->second.last_mstep;
 }
 
 extern "C" int rlvi_device_cus(void) { return rlvi::device_info().cus; }

@@ -17,11 +17,13 @@
 //
 // Same arithmetic, operation for operation, as the three-launch composition in aux.hip
 // (rlvi_mstep_fwd_bwd_f32 -> rlvi_estep_deep_f32 -> rlvi_mstep_fwd_bwd_f32): pi, the loss rows and
-// the gradient are bit-identical to it (tests/test_gpu_parity.py).  Eligibility: fp32, dense rows,
-// 4 | C, 32 <= C <= 128 (four lanes per row there too), 16 | B, 64 <= ceil(B/256) <= the co-resident workgroups of this device.
-// Below that, the rows stay in REGISTERS (further down): C <= 16 a row per thread (64 <= B <= 65 536), wider rows
-// four lanes per row (4 | C, C <= 128, 64 <= B <= 16 384).  Everything else (bf16, rows that are no multiple of
-// four columns, strided rows) takes the composition.
+// the gradient are bit-identical to it where the E-step slices coincide (tests/test_gpu_parity.py).
+// Dispatch (try_launch_fused_em, in this order): C <= 16: a row per thread, rows in REGISTERS (64 <= B <= 65 536);
+// 4 | C, 16 < C <= 128, 64 <= B <= 16 384: four lanes per row, rows in registers; then this LDS-resident kernel:
+// fp32, dense rows, 4 | C, 32 <= C <= 128 (four lanes per row there too), 16 | B, 64 <= ceil(B/256) <= the
+// co-resident workgroups of the device -- i.e. 16 385 <= B <= 65 536, and 16 129 <= B <= 16 384 when the register
+// form is refused for lack of co-resident workgroups.  Everything else (bf16, rows that are no multiple of four
+// columns, strided rows, more than 65 536 rows) takes the composition.
 #include "rlvi_trajb.h"
 
 namespace rlvi {
@@ -580,7 +582,9 @@ int try_launch_fused_em(const float *logits, int64_t ld, const int64_t *labels, 
                          inv_scale, tol, maxiter, grad, out, out_iters, ws, dbg, G, verify);
             return 1;
         };
-        return C <= 64 ? go(fused_em_rows4_kernel<4>) : go(fused_em_rows4_kernel<8>);
+        if (C <= 64 ? go(fused_em_rows4_kernel<4>) : go(fused_em_rows4_kernel<8>)) return 1;
+        // (refused -- fewer than 64 co-resident workgroups of that kernel, e.g. under RLVI_DEVICE_SHARERS: the
+        //  LDS-resident kernel below may still take the shape before the three-launch composition does)
     }
     if (grad == nullptr || ld != C || ldg != C || (C & 3) || C < 32 || C > 128 || (B & 15)) return 0;
     if (((uintptr_t)logits & 15) || ((uintptr_t)grad & 15)) return 0;

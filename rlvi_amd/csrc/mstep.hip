@@ -737,8 +737,10 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
                                   : go(mstep_wave_kernel<T, V, G, KMAX, WPB16, false>);
                 nb = nb16;
                 cuwide_done = true;
+                ws_note_mstep(ws, 3);
             }
         }
+        if (!cuwide_done) ws_note_mstep(ws, 2 + (hold_ticks != 0 ? 16 : 0));
         if (cuwide_done) {
         } else if (kact == KMAX)
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, true>, dim3((unsigned)nb), dim3(WPB * WAVE),
@@ -763,6 +765,7 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         if (nb > max_blocks) nb = max_blocks;
         if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
         if (nb < 1) nb = 1;
+        ws_note_mstep(ws, 1);
         rc = launch(mstep_kernel<T, V, G, KMAX>, dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st,
                     logits, ld, labels, idx, weights, residuals, N, B, C, kact, inv_scale, grad, ldg,
                     part, status, accum, inv_rows100, (int64_t)0);

@@ -34,6 +34,7 @@ int tune_get(const char *name, int dflt);
 enum { WSOPT_LOGITS_FROM_HBM = 0, WSOPT_COLD_START = 1, WSOPT_COUNT = 2 };
 int ws_option(const void *ws, int which, int dflt);
 void ws_options_forget(const void *ws);
+void ws_note_mstep(const void *ws, int code);      // which M-step form the last launch on `ws` took (tests)
 // Workgroups that are provably co-resident given the occupancy API's answer for one CU.
 int coop_blocks_from_occupancy(int per_cu_api, int block_threads, int cus);
 // Number of co-resident workgroups of `kernel` (block threads, dynamic LDS bytes) on this device.

@@ -944,16 +944,19 @@ __global__ __launch_bounds__(256) void truncate_kernel(float *__restrict__ w, in
 // Larger: the generic form, one workgroup, streaming.
 template <bool TRUNC>
 static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_t *mask,
-                            int64_t *kept, void *ws, hipStream_t st, int64_t n_all = 0, int sharded = 0) {
+                            int64_t *kept, void *ws, hipStream_t st, int64_t n_all = 0, int sharded = 0,
+                            int dry_run = 0) {
+    // dry_run: only say whether a launch would be admitted for this shape with the co-residency this process is
+    // entitled to (rlvi_threshold_sharded_check); nothing is launched, ws may be NULL
     const int64_t Nall = sharded ? n_all : N;
-    PeerTable *pt = sharded ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
-    unsigned long long *dbg = tune_get("RLVI_THR_DEBUG", 0)
+    PeerTable *pt = (sharded && !dry_run) ? reinterpret_cast<PeerTable *>(static_cast<char *>(ws) + WS_PEER_OFF) : nullptr;
+    unsigned long long *dbg = (!dry_run && tune_get("RLVI_THR_DEBUG", 0))
                                   ? reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF + 256)
                                   : nullptr;
     int rc = RLVI_E_LIMIT;
     bool launched = false;
     // 0: never use the last call's key as a guess (lab knob; the caller's form: the workspace option "cold_start")
-    const int use_state = tune_get("RLVI_THR_WARM", (!sharded && ws_option(ws, WSOPT_COLD_START, 0)) ? 0 : 1);
+    const int use_state = tune_get("RLVI_THR_WARM", (!sharded && !dry_run && ws_option(ws, WSOPT_COLD_START, 0)) ? 0 : 1);
     // key-list finish once at most this many keys PER WORKGROUP (on average) are left inside the prefix; 0: never
     const int list_per_wg = tune_get("RLVI_THR_LIST", 4);
 #define RLVI_THQ(E_, G_)                                                                         \
@@ -962,9 +965,10 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
         const int g_ = (G_);                                                                     \
         if (!launched && (g_ == 1 || coop_cap(kern, THQ_BLOCK) >= g_) &&                           \
             (N + g_ - 1) / g_ <= (int64_t)(E_) * THQ_BLOCK) {                                      \
-            rc = launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask,     \
-                        kept, ws, dbg, use_state, Nall, pt,                                        \
-                        list_per_wg * g_ < THQ_LIST_ALL ? list_per_wg * g_ : THQ_LIST_ALL);      \
+            rc = dry_run ? 0                                                                     \
+                         : launch(kern, dim3((unsigned)g_), dim3(THQ_BLOCK), 0, st, w, N, alpha, thr, mask, \
+                                  kept, ws, dbg, use_state, Nall, pt,                            \
+                                  list_per_wg * g_ < THQ_LIST_ALL ? list_per_wg * g_ : THQ_LIST_ALL); \
             launched = true;                                                                     \
         }                                                                                        \
     } while (0)
@@ -1002,6 +1006,7 @@ static int launch_threshold(float *w, int64_t N, float alpha, float *thr, uint8_
 #undef RLVI_THQ
     if (launched) return rc;
     if (sharded) return RLVI_E_LIMIT;            // (the one-workgroup forms see one rank's weights only)
+    if (dry_run) return 0;
     return launch(threshold_kernel<0, TRUNC>, dim3(1), dim3(THR_BLOCK), 0, st, w, N, alpha, thr, mask,
                   kept);
 }
@@ -1049,6 +1054,16 @@ extern "C" int rlvi_threshold_truncate_sharded_f32(float *weights, int64_t n_loc
     if (n_local <= 1024) return RLVI_E_LIMIT;
     return launch_threshold<true>(weights, n_local, alpha, thr_inout, mask_gt, kept_out, ws,
                                   static_cast<hipStream_t>(stream), n_all, 1);
+}
+
+// Would rlvi_threshold_truncate_sharded_f32 launch for this shape on this device, now?  0 = yes, RLVI_E_LIMIT =
+// no; nothing is launched (occupancy queries only).  The companion of rlvi_estep_sharded_check: every rank asks
+// both before the first sharded epoch end and the ranks compare answers (rlvi_amd.dist.set_owner_sharding) -- a
+// rank that cannot launch would leave the others spinning on its records until their bound.
+extern "C" int rlvi_threshold_sharded_check(int64_t n_local, int64_t n_all) {
+    if (n_local <= 0 || n_all < n_local) return RLVI_E_SHAPE;
+    if (n_all > (1ll << 29) || n_local <= 1024) return RLVI_E_LIMIT;
+    return launch_threshold<true>(nullptr, n_local, 0.05f, nullptr, nullptr, nullptr, nullptr, nullptr, n_all, 1, 1);
 }
 
 extern "C" int rlvi_truncate_f32(float *weights, int64_t N, const float *thr, uint8_t *mask_gt,

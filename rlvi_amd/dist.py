@@ -90,7 +90,7 @@ def declare_device_sharing(group=None):
 _OWNER = None
 
 
-def set_owner_sharding(owned, ws, peers, n_all=None, with_scalars=True):
+def set_owner_sharding(owned, ws, peers, n_all=None, with_scalars=True, maxiter=40):
     """Opt in to the collective-free epoch end of train_rlvi: every rank owns a FIXED set of samples
     (`owned`: 1-D int64 device tensor of their indexes; every sample owned by exactly one rank; the rank's
     loader yields only those) and keeps residuals / weights of its own samples only.  The E-step and the
@@ -115,8 +115,11 @@ def set_owner_sharding(owned, ws, peers, n_all=None, with_scalars=True):
         if n_all is not None and n_sum != int(n_all):
             raise RlviError(f"owner sharding: the ranks' shares {total} add up to {n_sum}, not to the "
                             f"{int(n_all)} samples of the vectors (every sample needs exactly one owner)")
+        # (both sharded launches of the epoch end, with the caller's maxiter: the E-step AND the threshold pick
+        #  their geometry per rank from the co-residency the process is entitled to)
         ok = (mine > 1024 and
-              _lib.load().rlvi_estep_sharded_check(mine, n_sum, 40, 1 if with_scalars else 0) == 0)
+              _lib.load().rlvi_estep_sharded_check(mine, n_sum, int(maxiter), 1 if with_scalars else 0) == 0 and
+              _lib.load().rlvi_threshold_sharded_check(mine, n_sum) == 0)
         oks = [None] * dist.get_world_size()
         dist.all_gather_object(oks, bool(ok))
         if not all(oks):

@@ -17,6 +17,11 @@ def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# the current stream's handle without building a torch.cuda.Stream object (MStepLoop asks once per batch)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
+    lambda dev: torch.cuda.current_stream(dev).cuda_stream)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -199,17 +204,18 @@ class MStepLoop:
         self._f32, self._bf16 = L.rlvi_mstep_fwd_bwd_f32, L.rlvi_mstep_fwd_bwd_bf16
         self._grads = {}
         self._dev = weights.device
+        self._devidx = weights.device.index if weights.device.index is not None else torch.cuda.current_device()
 
     def __call__(self, logits, labels, idx, inv_scale=None):
         dt = logits.dtype
         # the validated form, on the device and the stream the loop was made on; anything else -- strided or
         # other-typed logits, no index vector, a tensor on another device, a caller that has switched streams
         # inside the epoch -- takes the generic, fully checked wrapper (which launches on the CURRENT stream)
-        if not (idx is not None and logits.dim() == 2 and (dt is torch.float32 or dt is torch.bfloat16)
+        if not (idx is not None and (dt is torch.float32 or dt is torch.bfloat16) and logits.dim() == 2
                 and logits.is_contiguous() and labels.dtype is torch.int64 and idx.dtype is torch.int64
-                and logits.device == self._dev and labels.device == self._dev and idx.device == self._dev
                 and labels.is_contiguous() and idx.is_contiguous()
-                and torch.cuda.current_stream(self._dev).cuda_stream == self._stream):
+                and logits.device == self._dev and labels.is_cuda and idx.is_cuda
+                and _raw_stream(self._devidx) == self._stream):
             _require_gpu(logits, labels, idx)
             _, grad = mstep_fwd_bwd(logits.detach(), labels, idx, self.weights, self.residuals,
                                     inv_scale=inv_scale, accumulate=True, ws=self.ws)

@@ -963,6 +963,14 @@ def test_fused_em_one_launch_equals_the_three_launch_composition(B, C, gpu, orac
     rel, small = rel_pi(f[3], w2)
     assert rel <= REL and small <= 1e-7
     np.testing.assert_allclose(f[2], l2, rtol=REL, atol=1e-6)
+    # ... the weighted loss and the gradient with the NEW pi too (at every shape of this test, not at two): the
+    # oracle's M-step on the oracle's own posteriors, identity index, no scatter
+    ref = oracle.mstep(d["logits"], d["labels"], np.arange(B), w2, np.zeros(B, np.float32))
+    assert abs(float(f[0][0]) - float(ref["loss"])) <= REL * abs(float(ref["loss"]))
+    assert abs(float(f[0][1]) - float(ref["prec1"])) <= 1e-4
+    gd = f[1].astype(np.float64) - ref["grad"]
+    assert np.sqrt((gd ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+    assert np.abs(gd).max() <= 1e-6
 
 
 @pytest.mark.parametrize("B,C", [(4096, 10), (5003, 10), (45000, 10), (65536, 16), (20000, 7), (8192, 2),
@@ -1356,6 +1364,91 @@ def test_train_rlvi_epochs_golden(golden, gpu):
     assert torch.is_tensor(threshold) and threshold.dim() == 0
 
 
+def test_train_rlvi_with_bf16_logits_through_the_plugin(golden, gpu, oracle):
+    """cfg5's route (food.py:213-216 -> the same train_rlvi, a model whose head emits bf16): G4's four epochs
+    (overfit F, F, T, T) through the plug-in with bf16 logits -- MStepLoop's bf16 entry, the bf16 gradient handed
+    to logits.backward, the epoch end.  Every batch is held against the pinned oracle fed THE SAME bf16-rounded
+    logits as fp32 (that defines the bf16 target): the gradient the plug-in hands to autograd (compared
+    after the same bf16 rounding), the weight gradient that arrives at the parameters, and at the epoch end the
+    min-shifted residuals, pi, the threshold and train_acc of the oracle's epoch end on the oracle's own NLLs."""
+    torch, ops, dev = gpu
+    from rlvi_amd.methods import train_rlvi
+    g = golden("g4_epoch")
+    X, y = torch.from_numpy(g["X"]), torch.from_numpy(g["y"])
+    N, B = int(g["N"]), int(g["B"])
+
+    class Bf16Head(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(X.shape[1], 10)
+
+        def forward(self, x):
+            return self.lin(x).to(torch.bfloat16)
+
+    model = Bf16Head()
+    with torch.no_grad():
+        model.lin.weight.copy_(torch.from_numpy(g["W0"]))
+        model.lin.bias.copy_(torch.from_numpy(g["b0"]))
+    model.to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=float(g["lr"]), momentum=float(g["momentum"]))
+    residuals = torch.zeros(N, device=dev)
+    weights = torch.ones(N, device=dev)
+    threshold = 0
+    seen = []
+
+    def fwd_hook(_m, inp, out):
+        rec = {"x": inp[0].detach().clone(), "logits": out.detach().clone()}
+        out.register_hook(lambda gr, rec=rec: rec.__setitem__("grad", gr.detach().clone()))
+        seen.append(rec)
+    model.register_forward_hook(fwd_hook)
+    wgrads = []
+    model.lin.weight.register_hook(lambda gr: wgrads.append(gr.detach().clone()))
+    for ep in range(4):
+        perm = g["orders"][ep]
+        loader = [(X[perm[s:s + B]], y[perm[s:s + B]], torch.from_numpy(perm[s:s + B].astype(np.int64)))
+                  for s in range(0, N, B)]
+        overfit = bool(g[f"ep{ep}/overfit"])
+        w_before = weights.cpu().numpy().copy()
+        thr_before = float(threshold)
+        seen.clear()
+        wgrads.clear()
+        model.train()
+        acc, threshold = train_rlvi(loader, model, opt, residuals, weights, overfit, threshold)
+        torch.cuda.synchronize()
+        assert len(seen) == len(loader) == len(wgrads)
+        r_o = np.zeros(N, np.float32)
+        precs = []
+        for rec, (_, lab, idx), gw in zip(seen, loader, wgrads):
+            assert rec["logits"].dtype == torch.bfloat16 and rec["grad"].dtype == torch.bfloat16
+            z = rec["logits"].float().cpu().numpy()                 # the bf16-rounded logits as fp32
+            ref = oracle.mstep(z, lab.numpy(), idx.numpy(), w_before, r_o)
+            precs.append(float(ref["prec1"]))
+            want = torch.from_numpy(ref["grad"]).to(torch.bfloat16).float().numpy()
+            got = rec["grad"].float().cpu().numpy()
+            # one bf16 ulp where the rounding boundary is straddled, 1e-7 absolute for cancelling label entries
+            np.testing.assert_allclose(got, want, rtol=2 ** -7, atol=1e-7)
+            # ... and what autograd makes of it at the parameters: grad_W = grad^T x, from the bf16 gradient as is
+            gw_ref = rec["grad"].float().t() @ rec["x"]
+            np.testing.assert_allclose(gw.cpu().numpy(), gw_ref.cpu().numpy(), rtol=1e-4, atol=1e-7)
+        w_o = w_before.copy()
+        oracle.update_sample_weights(r_o, w_o)
+        thr_o = thr_before
+        if overfit:
+            thr_o = max(thr_before, float(oracle.false_negative_criterion(w_o)))
+            near = np.abs(w_o - np.float32(thr_o)) <= 1e-5 * max(thr_o, 1e-30)      # truncation near-ties
+            oracle.truncate(w_o, np.float32(thr_o))
+        else:
+            near = np.zeros(N, bool)
+        np.testing.assert_allclose(residuals.cpu().numpy(), r_o, rtol=REL, atol=2e-6)
+        wg = weights.cpu().numpy()
+        rel, small = rel_pi(wg[~near], w_o[~near])
+        assert rel <= REL and small <= 1e-7, (ep, rel, small)
+        assert abs(float(threshold) - thr_o) <= 1e-5 * max(thr_o, 1e-30) + 1e-7
+        assert acc == pytest.approx(float(np.mean(precs)), abs=1e-3)
+    assert torch.is_tensor(threshold) and threshold.dim() == 0
+    assert dev_status(ops, dev) == 0
+
+
 def test_weighted_ce_autograd(gpu, oracle):
     torch, ops, dev = gpu
     B, C = 200, 10
@@ -1556,6 +1649,58 @@ def test_small_loss_baselines_train_loops(gpu):
         assert test_acc > 85.0, (which, test_acc, "every batch matched stock torch" if which == "usdnl" else "")
     assert len(checked) == n_epoch * 16
     assert ops.workspace(dev).status() == 0
+
+
+def test_hbm_hint_is_per_workspace_two_loops_on_two_streams(gpu, oracle):
+    """The caller's "logits stream from HBM" hint lives with the caller's workspace (ABI 3; a process-wide knob in
+    round 3): two MStepLoops on two streams, one hinted and one not, each keep their own form -- the hinted one the
+    four-wave workgroups with the timed hold (form 2 + 16), the other the 16-wave barrier form (3) -- launch on
+    their own streams, and hand out the same bits."""
+    torch, ops, dev = gpu
+    from rlvi_amd import _lib
+    L = _lib.load()
+    B, C = 65536, 100
+    d = synth.mstep_inputs(B, C, seed=31)
+    z = torch.from_numpy(d["logits"]).to(dev)
+    lab, idx = torch.from_numpy(d["labels"]).to(dev), torch.from_numpy(d["idx"]).to(dev)
+    w = torch.from_numpy(d["weights"]).to(dev)
+    s_a, s_b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s_a):
+        ws_a = ops.Workspace(dev, B, B)
+        ops.hint_logits_from_hbm(ws_a, True)
+        res_a = torch.zeros(B, device=dev)
+        loop_a = ops.MStepLoop(w, res_a, ws_a)
+    with torch.cuda.stream(s_b):
+        ws_b = ops.Workspace(dev, B, B)
+        res_b = torch.zeros(B, device=dev)
+        loop_b = ops.MStepLoop(w, res_b, ws_b)
+    for _ in range(2):                                   # interleaved: neither launch changes the other's form
+        with torch.cuda.stream(s_a):
+            g_a = loop_a(z, lab, idx)
+        with torch.cuda.stream(s_b):
+            g_b = loop_b(z, lab, idx)
+        assert L.rlvi_workspace_last_mstep_form(ws_a.ptr) == 2 + 16
+        assert L.rlvi_workspace_last_mstep_form(ws_b.ptr) == 3
+    # a loop called under ANOTHER current stream than the one it was made on falls back to the checked wrapper,
+    # which launches on the current stream (never silently on the captured one)
+    with torch.cuda.stream(s_b):
+        g_a2 = loop_a(z, lab, idx).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(g_a, g_b) and torch.equal(g_a2, g_a) and torch.equal(res_a, res_b)
+    ref = oracle.mstep(d["logits"], d["labels"], d["idx"], d["weights"], np.zeros(B, np.float32))
+    diff = g_a.cpu().numpy().astype(np.float64) - ref["grad"]
+    assert np.sqrt((diff ** 2).sum()) <= REL * np.sqrt((ref["grad"].astype(np.float64) ** 2).sum())
+    with torch.cuda.stream(s_a):
+        out_a = ops.mstep_reduce(ws=ws_a).cpu().numpy()
+    with torch.cuda.stream(s_b):
+        out_b = ops.mstep_reduce(ws=ws_b).cpu().numpy()
+    # three launches accumulated on ws_a (two of its own stream + the fall-back call), two on ws_b
+    np.testing.assert_allclose(out_a[2] / 3.0, out_b[2] / 2.0, rtol=1e-6)
+    assert ws_a.status() == 0 and ws_b.status() == 0
+    # without the list argument the generic wrapper takes idx = None as the identity (evaluation / in-batch form)
+    assert loop_b(z[:64], lab[:64], None) is not None
+    ops.mstep_reduce(ws=ws_b)
 
 
 def test_calls_with_out_do_not_disturb_an_accumulate_sequence(gpu, oracle):
