@@ -355,7 +355,8 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
     float *__restrict__ residuals, int64_t N, int64_t nfull, int C, float inv_scale,
     T *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status, int accum,
-    double inv_rows100, int hold_ticks, int gen_ticks) {
+    double inv_rows100, int hold_ticks, int gen_ticks, unsigned long long *__restrict__ hold_slot,
+    unsigned long long hold_key, int hold_cap, int hold_pct) {
     constexpr int R = WAVE / G;                                   // rows per wave tile
     constexpr int VB = V * (int)sizeof(T);                        // bytes of a lane vector
     constexpr int NI = (KMAX * VB + 15) / 16;                     // 1-KiB pieces per tile (max)
@@ -412,7 +413,18 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
     // read / write stream (5.4 TB/s instead of 6.5 read-only), and the write burst that follows the read
     // phase is absorbed by the Infinity Cache and drains while the next launch is being dispatched:
     // 11.15 -> 10.5 us per launch at 65 536 x 100 (hold 4.0 us; 3.0 and 6.0 us are both slower than none).
-    const unsigned long long t_begin = hold_ticks > 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_begin = (hold_ticks > 0 || hold_slot != nullptr) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // Self-timed form (hold_slot != nullptr; what a chip-filling one-tile-per-wave launch takes by default): the
+    // hold is not an estimate of anybody's -- it is how long the PREVIOUS launch of this shape on this workspace
+    // needed to get its tile loads ISSUED, chip-wide (the issue is back-pressured by what the memory system
+    // returns, so "the last load is in flight" is when the read phase is as good as over; the per-CU barrier of
+    // the 16-wave form waits for exactly that moment, per CU).  A few waves of the launch's last workgroups --
+    // the ones a CU starts last -- leave (time bucket << 24 | ticks from their own start to their last load's
+    // issue) in the slot with one no-return atomic max: a later launch's stamps supersede an earlier one's, inside
+    // a launch the latest bucket's largest value stays.  Logits from the Infinity Cache get their loads issued
+    // sooner, so their hold is shorter by itself: no caller hint, no fitted rate.
+    unsigned long long slot_key = 0ull, slot_val = 0ull, t_issued = 0ull;
+    if (hold_slot != nullptr) { slot_key = hold_slot[0]; slot_val = hold_slot[1]; }
 
     // CUWIDE (WPB == 16: ONE workgroup per CU, all of its 16 waves): a workgroup barrier right behind the ISSUE
     // of a wave's tile loads -- no wave of the CU sends a store into the CU's memory pipeline before every wave
@@ -457,6 +469,11 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
         for (int i = 0; i < NI; ++i)
             stg[i] = __builtin_nontemporal_load(reinterpret_cast<const vu4 *>(src + dma_off[i]));
         RLVI_STAMP(1);
+        if (hold_slot != nullptr) {
+            __builtin_amdgcn_sched_barrier(0);       // (the loads are issued, THEN the clock is read)
+            t_issued = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (CUWIDE) {
             __builtin_amdgcn_sched_barrier(0);       // (the loads are issued, THEN the barrier)
             __builtin_amdgcn_s_barrier();
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
 #pragma unroll
         for (int i = 0; i < NI; ++i) tile16[i * WAVE + lane] = stg[i];
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(y64), "+v"(ix) : : "memory");
+        if (hold_slot != nullptr && hold_pct < 0) t_issued = __builtin_amdgcn_s_memrealtime();      // (lab: "landed")
         pi = weights != nullptr ? weights[ix] : 1.0f;
 #endif
 #endif
@@ -582,6 +600,21 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
 #else
 #define RLVI_TILE_STORE(val, ptr) (*(ptr) = (val))
 #endif
+        if (hold_slot != nullptr) {
+            const int pct = hold_pct < 0 ? -hold_pct : hold_pct;
+            long long h = slot_key == hold_key ? (long long)(slot_val & 0xFFFFFFull) * pct / 100 : 0ll;
+            h = h > hold_cap ? hold_cap : h;
+            while ((long long)(__builtin_amdgcn_s_memrealtime() - t_begin) < h) __builtin_amdgcn_s_sleep(4);
+            // the reporters: the last wave of every 16th workgroup of the launch's last quarter
+            if (lane == 0 && wave == WPB - 1 && (blockIdx.x & 15u) == 15u && blockIdx.x * 4u >= gridDim.x * 3u) {
+                unsigned long long dt = t_issued - t_begin;
+                dt = dt > 0xFFFFFFull ? 0xFFFFFFull : dt;
+                typedef __attribute__((address_space(1))) unsigned long long gull;
+                __hip_atomic_store((gull *)hold_slot, hold_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max((gull *)(hold_slot + 1), ((t_issued >> 6) << 24) | dt, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (hold_ticks > 0) {
             while (__builtin_amdgcn_s_memrealtime() - t_begin < (unsigned long long)hold_ticks)
                 __builtin_amdgcn_s_sleep(4);
@@ -632,6 +665,9 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
 // 13.6 MB bf16 -> 2.4 us, 16.8 MB -> 2.9, 19.7 MB -> 3.4, 26.2 MB -> 4.3, 33.5 MB -> 5.2): 0.68 us of ramp-up
 // + bytes / 7.25 TB/s; within +-0.3 us of the best hold most of the gain stays, 1 us off is worse than
 // none.  Below 12 MB no hold was found to help (the launch is over before the phases could separate).
+#ifndef RLVI_MSTEP_AUTO_DEFAULT
+#define RLVI_MSTEP_AUTO_DEFAULT 0
+#endif
 static inline int mstep_hold_ticks(double bytes) {
     if (bytes < 12.0e6) return 0;
     return (int)((0.68 + bytes / 7.25e6) * 100.0);
@@ -710,13 +746,28 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
         if (grad == nullptr || (nfull > waves && gen_ticks <= 0 && hold_ticks < 0)) hold_ticks = 0;
         if (hold_ticks < 0) hold_ticks = mstep_hold_ticks(gen_bytes);
         if (hold_ticks == 0) gen_ticks = 0;
+        // the self-timed hold (see the kernel): a chip-filling launch with one tile per wave that writes a gradient
+        // and reads at least 12 MB (below that no hold was found to help), unless the caller or the lab said
+        // something else.  RLVI_MSTEP_AUTO=0: the 16-wave barrier form of round 3 instead.
+        unsigned long long *hold_slot = nullptr;
+        unsigned long long hold_key = 0ull;
+        int hold_cap = 0;
+        const int hold_pct = tune_get("RLVI_MSTEP_AUTO_PCT", 100);
+        if (tune_get("RLVI_MSTEP_AUTO", RLVI_MSTEP_AUTO_DEFAULT) && grad != nullptr && hold_ticks == 0 &&
+            nfull <= waves && gen_bytes >= 12.0e6) {
+            hold_key = ((unsigned long long)nfull << 32) ^ ((unsigned long long)C * sizeof(T) << 8) ^ (unsigned)WPB;
+            WsHeader *hdr = reinterpret_cast<WsHeader *>(base);
+            hold_slot = &hdr->mstep_hold[(unsigned)((nfull * 31 + C * (int)sizeof(T)) & 3)][0];
+            hold_cap = mstep_hold_ticks(gen_bytes) * 3 / 2;      // (a stamp of a descheduled wave must not stall a launch)
+        }
         bool cuwide_done = false;
         if constexpr (G == 4 && V * sizeof(T) == 16) {
             constexpr int WPB16 = 16;
             int64_t nb16 = (nfull + WPB16 - 1) / WPB16;
             // (a caller that has hinted HBM-resident logits gets the four-wave workgroups with the timed hold:
             //  10.65 against 10.95 us -- the timed hold separates the phases chip-wide, the barrier per CU)
-            if (tune_get("RLVI_MSTEP_CUWIDE", 1) && grad != nullptr && hold_ticks == 0 && nb16 <= cus &&
+            if (tune_get("RLVI_MSTEP_CUWIDE", 1) && grad != nullptr && hold_ticks == 0 && hold_slot == nullptr &&
+                nb16 <= cus &&
                 nb16 * 5 >= (int64_t)cus * 4 && nb16 <= MSTEP_MAX_BLOCKS) {
                 const size_t lds16 = (size_t)WPB16 * SKB * 1024;
                 auto go = [&](auto kern) {
@@ -731,7 +782,7 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
                     }
                     return launch(kern, dim3((unsigned)nb16), dim3(WPB16 * WAVE), lds16, st, logits, labels, idx,
                                   weights, residuals, N, nfull, C, inv_scale, grad, part, status, accum, inv_rows100,
-                                  hold_ticks, 0);
+                                  hold_ticks, 0, (unsigned long long *)nullptr, 0ull, 0, 100);
                 };
                 rc = kact == KMAX ? go(mstep_wave_kernel<T, V, G, KMAX, WPB16, true>)
                                   : go(mstep_wave_kernel<T, V, G, KMAX, WPB16, false>);
@@ -740,16 +791,16 @@ static int launch_mstep(const T *logits, int64_t ld, const int64_t *labels, cons
                 ws_note_mstep(ws, 3);
             }
         }
-        if (!cuwide_done) ws_note_mstep(ws, 2 + (hold_ticks != 0 ? 16 : 0));
+        if (!cuwide_done) ws_note_mstep(ws, 2 + (hold_ticks != 0 ? 16 : 0) + (hold_slot != nullptr ? 32 : 0));
         if (cuwide_done) {
         } else if (kact == KMAX)
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, true>, dim3((unsigned)nb), dim3(WPB * WAVE),
                         lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
-                        part, status, accum, inv_rows100, hold_ticks, gen_ticks);
+                        part, status, accum, inv_rows100, hold_ticks, gen_ticks, hold_slot, hold_key, hold_cap, hold_pct);
         else
             rc = launch(mstep_wave_kernel<T, V, G, KMAX, WPB, false>, dim3((unsigned)nb), dim3(WPB * WAVE),
                         lds, st, logits, labels, idx, weights, residuals, N, nfull, C, inv_scale, grad,
-                        part, status, accum, inv_rows100, hold_ticks, gen_ticks);
+                        part, status, accum, inv_rows100, hold_ticks, gen_ticks, hold_slot, hold_key, hold_cap, hold_pct);
         const int64_t done = nfull * R;
         if (rc == 0 && done < B) {
             // the B mod R trailing rows: one workgroup of the register-row kernel, adding to record 0

@@ -80,8 +80,14 @@ struct WsHeader {
     uint32_t pad1[63];
     uint32_t epoch_base;     // tag base of the exchange slots (advanced by every coop kernel)
     uint32_t pad2[63];
+    // self-timed reads-then-writes hold of the M-step (mstep.hip): four slots {shape key, (time bucket << 24) | ticks}
+    // -- how long the LAST launch of that shape took to get its tile loads issued, chip-wide; the next launch holds
+    // its stores that long
+    unsigned long long mstep_hold[4][2];
+    uint32_t pad3[48];
 };
-constexpr size_t WS_HDR_BYTES = sizeof(WsHeader);                       // 768
+constexpr size_t WS_HDR_BYTES = sizeof(WsHeader);                       // 1024
+static_assert(sizeof(WsHeader) == 1024, "the header ends where the exchange slots begin");
 constexpr size_t WS_XCHG_OFF = 1024;
 constexpr int XCHG_GRANULES = 4;                                        // per workgroup
 // every record is published in XCHG_REPLICAS copies and a workgroup polls copy (blockIdx % 8): 256

@@ -123,6 +123,10 @@ with torch.cuda.stream(side):
         sys.exit(0)
     best = time_leg()
     extra = describe(best)
+    if any(t.startswith("RLVI_MSTEP_AUTO=1") for t in a.tune):
+        import numpy as np
+        hs = ws.buf[768:768 + 64].cpu().numpy().view(np.uint64).reshape(4, 2)
+        print("   hold slots (key, ticks of 10 ns):", [(hex(int(k)), int(v) & 0xFFFFFF) for k, v in hs if k])
     if a.what in ("thr", "thr_fn") and any(t.startswith("RLVI_THR_DEBUG") for t in a.tune):
         import numpy as np
         off = ops.debug_scratch_offset() + 256
