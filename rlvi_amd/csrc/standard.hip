@@ -37,6 +37,7 @@ typedef double sd4_t __attribute__((ext_vector_type(4)));
 constexpr int SL_THREADS = 256;
 constexpr int SL_NW = SL_THREADS / WAVE;
 constexpr int SL_DP = 32;                         // [X | y] padded to two 16-column blocks: d <= 31
+constexpr int SL_XS = 64;                          // 4-row k-panels a wave keeps in registers (resident design: n <= 1024)
 constexpr int SL_RU = 4;                           // 16-row blocks of the residual pass in flight per wave and trip
 constexpr int SL_GU = 16;                          // 4-row k-panels of the Gram loop in flight per wave and trip
 constexpr int SL_MAXN = 4096;                     // samples the one-workgroup form takes (16 per thread)
@@ -99,24 +100,55 @@ struct SlShared {
     double *rhs;        // [SL_DP] X^T W y
     double *slots;      // [2][SL_NW][2]
     int *flag;          // [4]
+    double *x1s;        // [1024][8]  columns 16 .. 23 of [X | y] (resident design with two column blocks)
 };
 
 // theta = argmin sum_i w_i (y_i - x_i.theta)^2 from the weights in sh.wsh -> sh.th[0 .. d).  Returns false (on
-// every thread) when a pivot is not safely positive.  All threads call.  DP: the system is solved padded to DP
-// rows (16, 24 or 32 >= d) -- straight-line code, no guard inside the factorisation.
-template <int DP>
+// every thread) when a pivot is not safely positive.  All threads call.  DS: the system is solved padded to DS >= d
+// rows -- straight-line code, no guard inside the factorisation; NB: 16-column blocks of [X | y] (2 when d >= 16).
+// RES: the design is RESIDENT on the chip (n <= 1024, d <= 23): lane (i, kk) of wave w keeps
+// [X | y][4 (w + 4 k) + kk][i], k < 64, in registers (xr) and columns 16 .. 23 live in LDS (sh.x1s) -- no pass over
+// global memory after the first.
+template <int DS, int NB, bool RES>
 __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restrict__ X, const double *__restrict__ y,
-                                       int n, int d) {
+                                       int n, int d, const double (&xr)[RES ? SL_XS : 1]) {
+    constexpr int DP = NB * 16;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int i = lane & 15, kk = lane >> 4;
     sd4_t a00 = {0.0, 0.0, 0.0, 0.0}, a01 = a00, a11 = a00;
     const int steps = (n + 3) / 4;
+    if constexpr (RES) {
+        const int c1 = (i & 7) * 1;
+#pragma unroll
+        for (int k0 = 0; k0 < SL_XS; k0 += 8) {
+            if (4 * (wave + SL_NW * k0) < n) {                        // (wave-uniform: a short design skips its empty blocks)
+                double w[8], x1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = 4 * (wave + SL_NW * (k0 + u)) + kk;      // < 1024 = the padded length of wsh / x1s
+                    w[u] = sh.wsh[row];                              // rows past n: weight 0, panel 0
+                    x1[u] = NB > 1 ? sh.x1s[row * 8 + c1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double x0 = xr[k0 + u];
+                    const double w0 = w[u] * x0;
+                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, x0, a00, 0, 0, 0);
+                    if (NB > 1) {
+                        const double xb = i < 8 ? x1[u] : 0.0;
+                        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, xb, a01, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u] * xb, xb, a11, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else
     // SL_GU k-panels (4 rows each) per trip, all their loads in flight together: the design comes from the L2
     // (160 KB at n = 1000, d = 20) and a trip's registers are free again before the factorisation needs its own.
     // One CU streams from the L2 at ~45 GB/s (its outstanding misses x the L2's latency), so a pass over the
     // design is microseconds whatever the loop looks like: in-kernel stamps (tools/lab/linreg_phases.py) put this
     // pass and the residual pass at the top of the launch's time beside the E-step's serial reductions.
-    for (int s0 = wave; s0 < steps; s0 += SL_GU * SL_NW) {
+    for (int s0 = wave; s0 < steps; s0 += SL_GU * SL_NW) {      // (the body of `else` when RES)
         double x0[SL_GU], x1[SL_GU], w[SL_GU];
         int xrow0[SL_GU];
 #pragma unroll
@@ -166,7 +198,7 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
     }
     SL_STAMP();   // gram loop done
     // the waves' partial blocks -> LDS; element e of a block = (result r, lane): row (lane >> 4) + 4 r, column lane & 15
-    constexpr int NBLK = DP > 16 ? 3 : 1;
+    constexpr int NBLK = NB > 1 ? 3 : 1;
     double *my = sh.red + (size_t)wave * 3 * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -200,9 +232,9 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
         // (opaque: the lane masks t > j, t == j below are loop-invariant across the estimator's outer loop, and
         //  hoisted there they are 2 DP scalar register pairs that spill)
         asm volatile("" : "+v"(t));
-        double g[DP];
+        double g[DS];
 #pragma unroll
-        for (int c = 0; c < DP; ++c) g[c] = sh.G[t * SL_GPITCH + c];
+        for (int c = 0; c < DS; ++c) g[c] = sh.G[t * SL_GPITCH + c];
         double b = t < d ? sh.rhs[t < SL_DP ? t : 0] : 0.0;
         double dmax = t < d ? sh.G[t * SL_GPITCH + t] : 0.0;
         dmax = wave_max(dmax);
@@ -210,14 +242,14 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
         bool bad = !(dmax == dmax);
         double dinv = 0.0;                       // lane j: 1 / D_j
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {
+        for (int j = 0; j < DS; ++j) {
             const double piv = sl_readlane(g[j], j);
             bad = bad || (j < d && !(piv > piv_min));
             const double inv = sl_rcp(piv);
             const double l = g[j] * inv;                              // L[t][j] for t > j
             dinv = t == j ? inv : dinv;
 #pragma unroll
-            for (int c = j + 1; c < DP; ++c) {
+            for (int c = j + 1; c < DS; ++c) {
                 const double lc = sl_readlane(g[j], c);              // G[c][j] = L[c][j] D_j
                 g[c] = __builtin_fma(-l, lc, g[c]);                  // (lanes t < c compute values nobody reads)
                 // (eight broadcasts at a time: all 31 of a pivot hoisted at once do not fit the scalar registers)
@@ -229,16 +261,16 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
         }
         // L z = b (lane t ends with z_t; g[j] = 0 for t <= j: no mask), then z / D
 #pragma unroll
-        for (int j = 0; j < DP; ++j) b = __builtin_fma(-g[j], sl_readlane(b, j), b);
+        for (int j = 0; j < DS; ++j) b = __builtin_fma(-g[j], sl_readlane(b, j), b);
         b *= dinv;
         // L^T theta = z: lane t needs column t of L = row t of L^T (0 for c <= t: no mask)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int c = 0; c < DP; ++c) g[c] = sh.LT[c * 0 + t * SL_GPITCH + c];
+        for (int c = 0; c < DS; ++c) g[c] = sh.LT[t * SL_GPITCH + c];
 #pragma unroll
-        for (int j = DP - 1; j >= 1; --j) b = __builtin_fma(-g[j], sl_readlane(b, j), b);
+        for (int j = DS - 1; j >= 1; --j) b = __builtin_fma(-g[j], sl_readlane(b, j), b);
         if (lane < d) sh.th[lane] = b;
         if (lane == 0) sh.flag[0] = bad ? 1 : 0;
     }
@@ -248,11 +280,70 @@ __device__ __forceinline__ bool sl_wls(const SlShared &sh, const double *__restr
 }
 
 // r_i = (y_i - x_i.theta)^2 -> sh.rsh, sigma2 = w.r / sum(w); returns sigma2 on every thread
+template <int NB, bool RES>
 __device__ __forceinline__ double sl_residuals(const SlShared &sh, const double *__restrict__ X,
-                                               const double *__restrict__ y, int n, int d, int &parity) {
+                                               const double *__restrict__ y, int n, int d, int &parity,
+                                               const double (&xr)[RES ? SL_XS : 1]) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const int i = lane & 15, kk = lane >> 4;
     double num = 0.0, den = 0.0;
+    if constexpr (RES) {
+        // from the resident panels: lane (i, kk) holds [X | y][row][i] (and reads [row][16 + i], i < 8, from LDS); with
+        // c = [theta; -1 in column d] the row's x.theta - y is the sum over the 16 lanes of a row's group -- four
+        // DPP steps -- and its square is the residual.  No matrix instruction (they contract over the ROWS of a
+        // panel, which is the Gram matrix's sum), no byte from global memory.
+        const double c0 = i < d ? sh.th[i] : (i == d ? -1.0 : 0.0);
+        const int j1 = 16 + (i & 7);
+        const double c1 = (NB > 1 && i < 8) ? (j1 < d ? sh.th[j1 < SL_DP ? j1 : 0] : (j1 == d ? -1.0 : 0.0)) : 0.0;
+#pragma unroll
+        for (int k0 = 0; k0 < SL_XS; k0 += 8) {
+            // eight panels per block of straight-line code (their LDS reads and butterflies interleave); a short
+            // design skips its empty blocks (wave-uniform)
+            if (4 * (wave + SL_NW * k0) < n) {
+                double p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = 4 * (wave + SL_NW * (k0 + u)) + kk;
+                    p[u] = xr[k0 + u] * c0;
+                    if (NB > 1) p[u] = __builtin_fma(sh.x1s[row * 8 + (i & 7)], c1, p[u]);
+                }
+                // the eight partials of a lane -> the eight row sums of its 16-lane group, TRANSPOSING on the way:
+                // after the exchange with lane ^ 1 a lane keeps the panels of its own parity (four values), after
+                // lane ^ 2 two, and those two are finished by two rotations of the row -- 54 cross-lane instructions for
+                // eight panels instead of 96; lane (b2 b1) of a group ends with the sums of panels b2b1 and 4 + b2b1
+                const bool b1 = (i & 1) != 0, b2 = (i & 2) != 0;
+                double q[4], r[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double keep = b1 ? p[2 * m + 1] : p[2 * m], send = b1 ? p[2 * m] : p[2 * m + 1];
+                    q[m] = keep + dpp_x<0xB1>(send);                 // quad_perm [1,0,3,2]
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const double keep = b2 ? q[2 * m + 1] : q[2 * m], send = b2 ? q[2 * m] : q[2 * m + 1];
+                    r[m] = keep + dpp_x<0x4E>(send);                 // quad_perm [2,3,0,1]
+                    // (the partners of the last two steps must share the lane's low two bits: rotations by 8 and by 4
+                    //  inside the 16-lane row, not the mirrors)
+                    r[m] = r[m] + dpp_x<0x128>(r[m]);                // row_ror:8
+                    r[m] = r[m] + dpp_x<0x124>(r[m]);                // row_ror:4
+                }
+                // lanes 0 .. 3 of a group keep the sums and write the residuals of panels i and 4 + i
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int u = 4 * m + (i & 3);
+                    const int row = 4 * (wave + SL_NW * (k0 + u)) + kk;
+                    const double rr = r[m] * r[m];
+                    const double wr = i < 4 ? sh.wsh[row] : 0.0;
+                    if (i < 4) sh.rsh[row] = rr;
+                    num = __builtin_fma(wr, rr, num);
+                    den += wr;
+                }
+            }
+        }
+        sl_block_sum2(num, den, sh.slots, parity);
+        SL_STAMP();   // residuals done
+        return num / den;
+    }
     const int blocks = (n + 15) / 16;
     // X[16 rb .. +15] . theta on the matrix cores: A = a 16 x 4 panel of X, B = the 4 matching entries of theta in
     // every column; lane l's results are rows (l >> 4) + 4 r, all columns alike.  SL_RU row blocks per wave and
@@ -306,7 +397,7 @@ __device__ __forceinline__ double sl_residuals(const SlShared &sh, const double 
     return num / den;
 }
 
-template <int E, int DP>
+template <int E, int DS, int NB, bool RES>
 __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
     const double *__restrict__ X, const double *__restrict__ y, int n, int d, int npad, int maxiter, double tol,
     double etol, int emaxiter, double *__restrict__ theta_out, double *__restrict__ w_out,
@@ -328,9 +419,50 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
     sh.rhs = sh.th + 2 * SL_DP;
     sh.slots = sh.rhs + SL_DP;
     sh.flag = reinterpret_cast<int *>(sh.slots + 2 * SL_NW * 2);
+    sh.x1s = reinterpret_cast<double *>(sh.flag + 4);
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     int parity = 0;
 
+    // resident design: the k-panels of column block 0 into registers, columns 16 .. 23 into LDS -- once
+    double xr[RES ? SL_XS : 1];
+    if constexpr (RES) {
+        const int i = lane & 15, kk = lane >> 4;
+        if (i <= d) {                                  // (one branch around all loads: they are in flight together)
+#pragma unroll
+            for (int k = 0; k < SL_XS; ++k) {
+                const int row = 4 * (wave + SL_NW * k) + kk;
+                const int rr = row < n ? row : 0;
+                xr[k] = *(i < d ? X + (size_t)rr * d + i : y + rr);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SL_XS; ++k) xr[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < SL_XS; ++k) xr[k] = (4 * (wave + SL_NW * k) + kk < n) ? xr[k] : 0.0;
+        if (NB > 1) {
+            for (int q0 = tid; q0 < 1024 * 8; q0 += 8 * SL_THREADS) {        // eight loads in flight per thread
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u * SL_THREADS;
+                    const int row = q >> 3, col = 16 + (q & 7);
+                    const int rr = row < n ? row : 0;
+                    v[u] = *(col < d ? X + (size_t)rr * d + col : y + rr);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u * SL_THREADS;
+                    const int row = q >> 3, col = 16 + (q & 7);
+                    sl_keep(v[u]);
+                    sh.x1s[q] = (row < n && col <= d) ? v[u] : 0.0;
+                }
+            }
+        }
+    } else {
+        xr[0] = 0.0;
+    }
     for (int q = tid; q < npad; q += SL_THREADS) sh.wsh[q] = q < n ? 1.0 : 0.0;     // weights = ones (rlvi.py:69)
     for (int q = tid; q < 2 * SL_DP; q += SL_THREADS) sh.th[q] = 0.0;
     for (int q = tid; q < SL_DP * SL_GPITCH; q += SL_THREADS) sh.G[q] = 0.0;
@@ -343,9 +475,9 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
         SL_STAMP();   // outer iteration starts
         // theta from the current weights (rlvi.py:70-71 the first time, :79-80 afterwards), then the residuals
         // and sigma2 (:72-73, :81-82)
-        ok = sl_wls<DP>(sh, X, y, n, d);
+        ok = sl_wls<DS, NB, RES>(sh, X, y, n, d, xr);
         if (!ok) break;
-        const double sigma2 = sl_residuals(sh, X, y, n, d, parity);
+        const double sigma2 = sl_residuals<NB, RES>(sh, X, y, n, d, parity, xr);
         if (outer > 0) {
             // ||theta - prev|| / ||prev|| <= tol (rlvi.py:85-87): every wave from LDS, the same bits everywhere
             const double tn = lane < d ? sh.th[lane] : 0.0, tp = lane < d ? sh.th[SL_DP + lane] : 0.0;
@@ -551,9 +683,14 @@ extern "C" int rlvi_linear_regression_f64(const double *X, const double *y, int6
         ((uintptr_t)info & 3) || ((uintptr_t)ws & 255))
         return RLVI_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int npad_x = (int)((n + 63) / 64) * 64;
+    // (samples per thread: four up to n = 1024, sixteen beyond; the system solved padded to 12 / 16 / 20 / 24 / 32 rows;
+    //  one or two 16-column blocks of [X | y]; the design resident on the chip -- registers + LDS -- when n <= 1024
+    //  and d <= 23)
+    const bool two = d >= 16;                                     // column d (= y) needs the second block
+    const bool res = n <= 4 * SL_THREADS && d <= 23;
+    const int npad_x = res ? 1024 : (int)((n + 63) / 64) * 64;
     const size_t lds = ((size_t)2 * npad_x + (size_t)SL_NW * 3 * 256 + 2 * SL_DP * SL_GPITCH + 3 * SL_DP +
-                        2 * SL_NW * 2 + 2) * sizeof(double);
+                        2 * SL_NW * 2 + 2 + ((res && two) ? 1024 * 8 : 0)) * sizeof(double);
     auto go = [&](auto kern) {
         // (> 64 KiB of dynamic LDS: asked for once per kernel and device)
         static int attr_dev = -1;
@@ -569,16 +706,18 @@ extern "C" int rlvi_linear_regression_f64(const double *X, const double *y, int6
                       estep_tol, estep_maxiter, theta, weights, info,
                       reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + WS_SCRATCH_OFF));
     };
-    // (samples per thread: four up to n = 1024, sixteen beyond; the system padded to 16, 24 or 32 rows)
-    const int dp = d < 16 ? 16 : (d < 24 ? 24 : 32);
-    if (n <= 4 * SL_THREADS) {
-        if (dp == 16) return go(linreg_rlvi_kernel<4, 16>);
-        if (dp == 24) return go(linreg_rlvi_kernel<4, 24>);
-        return go(linreg_rlvi_kernel<4, 32>);
+    if (res) {
+        if (d <= 12) return go(linreg_rlvi_kernel<4, 12, 1, true>);
+        if (d <= 15) return go(linreg_rlvi_kernel<4, 16, 1, true>);
+        if (d <= 20) return go(linreg_rlvi_kernel<4, 20, 2, true>);
+        return go(linreg_rlvi_kernel<4, 24, 2, true>);
     }
-    if (dp == 16) return go(linreg_rlvi_kernel<16, 16>);
-    if (dp == 24) return go(linreg_rlvi_kernel<16, 24>);
-    return go(linreg_rlvi_kernel<16, 32>);
+    if (n <= 4 * SL_THREADS) return go(linreg_rlvi_kernel<4, 32, 2, false>);      // d = 24 .. 31
+    if (d <= 12) return go(linreg_rlvi_kernel<16, 12, 1, false>);
+    if (d <= 15) return go(linreg_rlvi_kernel<16, 16, 1, false>);
+    if (d <= 20) return go(linreg_rlvi_kernel<16, 20, 2, false>);
+    if (d <= 24) return go(linreg_rlvi_kernel<16, 24, 2, false>);
+    return go(linreg_rlvi_kernel<16, 32, 2, false>);
 }
 
 extern "C" int rlvi_sample_weight_online_f64(const double *X, const double *w, double b, int first, int64_t n,
