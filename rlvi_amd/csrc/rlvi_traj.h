@@ -105,7 +105,8 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
                                          float tD,
                                          float gmin, bool dead, float rn_l, float shift, float invN,
                                          float tol, float *trace, bool want_nodes, int xstep,
-                                         unsigned long long *dbg, float tR3 = 0.0f, float tR4 = 0.0f) {
+                                         unsigned long long *dbg, float tR3 = 0.0f, float tR4 = 0.0f,
+                                         bool cold = false) {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool has = lane < Ke;
     // RLVI_TJ_DEBUG: where the recurrence wave's time goes (first round of workgroup 0)
@@ -187,7 +188,9 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
     // (Measured: 62 ns per step = ~19 clocks per level of the seven-level dependent chain dr -> dr^2 ->
     //  Estrin pair -> avg -> 1 - avg -> rcp -> next dr; the six v_readlane of a step already issue in its
     //  stalls -- writing four steps per loop iteration side by side changed nothing.)
-    if (!scanned) {
+    // (cold: the nodes are the geometric default, not a guess of this trajectory -- the local chain would leave
+    //  its trust region at once; its 1.2 us are saved and the global model below takes the round)
+    if (!scanned && !cold) {
         if (HI) {
             // Fourth-order chain.  S(r' + d) = S + S' d - Q d^2 + R3 d^3 - R4 d^4 + ...  (alternating for
             // d > 0, terms falling by a factor <= |d|/r').  The arithmetic of a step is what it always was
@@ -263,8 +266,8 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
     // (25 % trust region for the local model: inside it one more round finishes -- the bench's
     //  data-to-data drift of 2-7 % stays on this path; beyond it the local model converges one
     //  node per round at worst)
-    const bool inside = !(has && lane < steps) ||
-                        (fabsf(rnew_l - rn) <= RLVI_TJ_TRUST * rn && avg_l > 0.0f && avg_l < 0.999999f);
+    const bool inside = !cold && (!(has && lane < steps) ||
+                        (fabsf(rnew_l - rn) <= RLVI_TJ_TRUST * rn && avg_l > 0.0f && avg_l < 0.999999f));
     if (!__all(inside)) {
         // Cold or poor guesses: the nodes are far from the trajectory, but together they sample
         // S(r) over its whole range.  s(u) = mean(pi) as a function of u = log r is a sum of
@@ -297,6 +300,32 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
         const unsigned long long vmask = __ballot(key < __builtin_inff());
         const int nv = (int)__popcll(vmask);
         auto rl = [](float v, int p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), p)); };
+        // The interpolant of every interval, once and lane-parallel (round 4): sorted position p holds the interval
+        // [node p-1, node p] as the six monomial coefficients of its Hermite polynomial in t = (u - u_a) / h, with
+        // u_a and 1 / h beside them, in the operand table -- a step of the chain below is then a logarithm, a ballot,
+        // two 16-byte LDS reads and a Horner scheme instead of ten v_readlane (each a scalar result the next vector
+        // instruction has to wait for) and the five basis polynomials: 0.26 -> 0.1 us per step of a cold start.
+        {
+            const float ua = lane_up1(key), fa = lane_up1(s0_s), da = lane_up1(s1_s), ea = lane_up1(s2_s);
+            const float h = key - ua;
+            const bool okiv = lane >= 1 && lane < nv && h > 1e-5f;
+            const float df = s0_s - fa, g0 = h * da, g1 = h * s1_s;
+            float c2, c3, c4 = 0.0f, c5 = 0.0f;
+            if (HASQ) {
+                const float q0 = h * h * ea, q1 = h * h * s2_s;
+                c2 = 0.5f * q0;
+                c3 = fmaf(10.0f, df, fmaf(-6.0f, g0, fmaf(-4.0f, g1, fmaf(-1.5f, q0, 0.5f * q1))));
+                c4 = fmaf(-15.0f, df, fmaf(8.0f, g0, fmaf(7.0f, g1, fmaf(1.5f, q0, -q1))));
+                c5 = fmaf(6.0f, df, fmaf(-3.0f, g0, fmaf(-3.0f, g1, fmaf(-0.5f, q0, 0.5f * q1))));
+            } else {
+                c2 = fmaf(3.0f, df, fmaf(-2.0f, g0, -g1));
+                c3 = fmaf(-2.0f, df, g0 + g1);
+            }
+            float *cf = out.coef[lane];
+            *reinterpret_cast<float4 *>(cf) = make_float4(fa, g0, c2, c3);
+            *reinterpret_cast<float4 *>(cf + 4) = make_float4(c4, c5, ua, okiv ? __builtin_amdgcn_rcpf(h) : -1.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
         r = (float)(0.95 / (1.0 - 0.95));
 #pragma unroll 1
         for (int step = 0; step < steps; ++step) {
@@ -307,28 +336,11 @@ __device__ __forceinline__ void tj_chain(TjOut &out, int Ke, int Ka, float tS, f
             float avg;
             bool done = false;
             if (p_hi > 0 && p_hi < nv) {
-                const float ua = rl(key, p_hi - 1), ub = rl(key, p_hi);
-                const float h = ub - ua;
-                if (h > 1e-5f) {
-                    const float sa = rl(s0_s, p_hi - 1), sb = rl(s0_s, p_hi);
-                    const float da = rl(s1_s, p_hi - 1), db = rl(s1_s, p_hi);
-                    const float t = (u - ua) * __builtin_amdgcn_rcpf(h);
-                    const float t2 = t * t, t3 = t2 * t;
-                    if (HASQ) {
-                        const float ea = rl(s2_s, p_hi - 1), eb = rl(s2_s, p_hi);
-                        const float w3 = t3 * fmaf(t, fmaf(6.0f, t, -15.0f), 10.0f);       // H3 = 1 - H0
-                        const float h1 = t - t3 * fmaf(t, fmaf(3.0f, t, -8.0f), 6.0f);
-                        const float h4 = t3 * fmaf(t, fmaf(-3.0f, t, 7.0f), -4.0f);
-                        const float h2 = 0.5f * t2 - t3 * fmaf(t, fmaf(0.5f, t, -1.5f), 1.5f);
-                        const float h5 = t3 * fmaf(t, fmaf(0.5f, t, -1.0f), 0.5f);
-                        avg = fmaf(w3, sb - sa, sa) + h * fmaf(da, h1, db * h4) +
-                              h * h * fmaf(ea, h2, eb * h5);
-                    } else {
-                        const float w3 = t2 * fmaf(-2.0f, t, 3.0f);                       // H3 = 1 - H0
-                        const float h1 = t - 2.0f * t2 + t3;
-                        const float h4 = t3 - t2;
-                        avg = fmaf(w3, sb - sa, sa) + h * fmaf(da, h1, db * h4);
-                    }
+                const float4 ca = *reinterpret_cast<const float4 *>(out.coef[p_hi]);
+                const float4 cb = *reinterpret_cast<const float4 *>(out.coef[p_hi] + 4);
+                if (cb.w > 0.0f) {
+                    const float t = (u - cb.z) * cb.w;
+                    avg = fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, cb.y, cb.x), ca.w), ca.z), ca.y), ca.x);
                     done = true;
                 }
             }

@@ -269,7 +269,9 @@ __device__ __forceinline__ TbSolved trajb_solve(
         constexpr bool HI_OK = TB_BLOCK == 256;
         // (verify -- RLVI_TJ_VERIFY=1 -- forces the verification round: no fourth-order first round, no
         //  acceptance on estimated step errors; the tests hold the two paths against each other)
-        const bool hi_round = HI_OK && round == 0 && trace == nullptr && !verify;
+        // (... and none without a guess: a cold start's first round goes to the global model whatever its sums
+        //  carry -- the two extra accumulators and granules would be 0.8 us for nothing)
+        const bool hi_round = HI_OK && round == 0 && trace == nullptr && !verify && wm.warm;
         gu64 *A = bufA + (size_t)(xstep & 1) * TJ_MAXK * MAX_COOP_WG * XCHG3_GRANULES;
         // (every replica on its own 3-KiB stretch: 256 pollers on one 768-byte stretch serialise at the
         //  memory side)
@@ -635,7 +637,7 @@ __device__ __forceinline__ TbSolved trajb_solve(
             else if (round == 0)
                 tj_chain<true>(sh.out, Ke, K, val[0], val[1], val[2], val[3],
                                gm, dead,
-                               rn_l, shift, invN, tol, trace, true, xstep, dbg);
+                               rn_l, shift, invN, tol, trace, true, xstep, dbg, 0.0f, 0.0f, !wm.warm);
             else
                 tj_chain<false>(sh.out, Ke, K, val[0], val[1], val[2], val[3],
                                gm, dead,
