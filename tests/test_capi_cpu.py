@@ -58,6 +58,53 @@ def test_argument_errors_without_a_gpu(lib):
     assert lib.rlvi_update_weights_f64(p, 0, 1e-3, 10, p, None, p, None) == -2
 
 
+def test_knobs_can_be_taken_back_and_listed(lib):
+    """rlvi_tune_set is process-wide: rlvi_tune_unset takes a value back (the environment / default applies again),
+    rlvi_tune_overrides lists what is set -- what the GPU suite's autouse fixture asserts to be empty after every
+    test.  Host-side only: no device needed."""
+    from rlvi_amd import _lib
+    for n in _lib.tune_overrides():
+        lib.rlvi_tune_unset(n.encode())
+    assert _lib.tune_overrides() == [] and lib.rlvi_tune_unset(b"RLVI_THR_LIST") == 0
+    assert lib.rlvi_tune_set(b"RLVI_THR_LIST", 7) == 0 and lib.rlvi_tune_set(b"RLVI_FUSED_EM", 0) == 0
+    assert sorted(_lib.tune_overrides()) == ["RLVI_FUSED_EM", "RLVI_THR_LIST"]
+    assert lib.rlvi_tune_set(b"RLVI_THR_LIST", 9) == 0 and len(_lib.tune_overrides()) == 2     # same knob, new value
+    assert lib.rlvi_tune_unset(b"RLVI_THR_LIST") == 1 and lib.rlvi_tune_unset(b"RLVI_THR_LIST") == 0
+    assert _lib.tune_overrides() == ["RLVI_FUSED_EM"]
+    assert lib.rlvi_tune_unset(b"RLVI_FUSED_EM") == 1 and _lib.tune_overrides() == []
+    assert lib.rlvi_tune_unset(None) == -1
+
+
+def test_workspace_regions_options_and_shape_queries(lib):
+    """Host-side queries of ABI 3: the named regions of the workspace layout lie inside the smallest workspace, in
+    order and apart; a per-workspace option is refused for an unknown name; the one-launch estimator says which
+    shapes it takes."""
+    n = ctypes.c_size_t(0)
+    small = lib.rlvi_workspace_bytes(0, 0)
+    offs = {}
+    for name in (b"warm", b"records", b"records_out", b"scratch"):
+        offs[name] = lib.rlvi_workspace_region(name, ctypes.byref(n))
+        assert 0 < offs[name] < small, name
+        if name != b"scratch":
+            assert n.value > 0
+    assert offs[b"warm"] < offs[b"records"] < offs[b"records_out"] < offs[b"scratch"]
+    assert offs[b"records_out"] - offs[b"records"] >= 1024 * 4 * 8          # 1024 workgroups x 4 doubles each
+    assert lib.rlvi_workspace_region(b"nope", None) == ctypes.c_size_t(-1).value
+    buf = (ctypes.c_char * 512)()
+    p = (ctypes.addressof(buf) + 255) & ~255
+    assert lib.rlvi_workspace_set_option(p, b"logits_from_hbm", 1) == 0
+    assert lib.rlvi_workspace_set_option(p, b"cold_start", 1) == 0
+    assert lib.rlvi_workspace_set_option(p, b"no_such_option", 1) == -2
+    assert lib.rlvi_workspace_set_option(None, b"cold_start", 1) == -1
+    assert lib.rlvi_workspace_last_mstep_form(p) == 0
+    assert lib.rlvi_linear_regression_check(1000, 20) == 0 and lib.rlvi_linear_regression_check(40, 10) == 0
+    assert lib.rlvi_linear_regression_check(4096, 31) == 0
+    assert lib.rlvi_linear_regression_check(4097, 5) == -5 and lib.rlvi_linear_regression_check(100, 32) == -5
+    assert lib.rlvi_linear_regression_check(0, 5) == -2
+    assert lib.rlvi_stream_copy(None, None, 16, None) == -1
+    assert lib.rlvi_stream_copy(p, p + 8, 16, None) == -3 and lib.rlvi_stream_copy(p, p + 16, 24, None) == -3
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from rlvi_amd import _lib, ops

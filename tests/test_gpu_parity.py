@@ -1703,6 +1703,43 @@ def test_hbm_hint_is_per_workspace_two_loops_on_two_streams(gpu, oracle):
     ops.mstep_reduce(ws=ws_b)
 
 
+@pytest.mark.parametrize("kind,N", [("bimodal", 65536), ("ce", 54000), ("heavy", 45000), ("zeros10", 75750),
+                                    ("exp", 4096), ("equal", 1000)])
+def test_estep_cold_start_option_and_warm_reset(kind, N, gpu, oracle):
+    """The workspace option `cold_start` (what bench.py's estep_cold_us runs: every call as the reference's loop starts
+    it, train_rlvi.py:29) and rlvi_workspace_reset_warm: the guesses never enter the RESULT -- cold, warm and
+    reset-then-warm calls give the oracle's iteration count and pi to 1e-5; two cold calls on one workspace are bit
+    for bit the same call (nothing of the first one is used by the second); the cold path is the global model with
+    its per-interval coefficient table (no local chain, no fourth-order sums: rlvi_traj.h)."""
+    torch, ops, dev = gpu
+    r0 = synth.residual_vector(kind, N, seed=17)
+    ro, wo = r0.copy(), np.ones(N, np.float32)
+    it_o = oracle.update_sample_weights(ro, wo)
+
+    def run(ws):
+        rt, wt = torch.from_numpy(r0.copy()).to(dev), torch.ones(N, device=dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.estep_deep(rt, wt, iters=iters, ws=ws)
+        torch.cuda.synchronize()
+        assert ws.status() == 0
+        return int(iters), wt.cpu().numpy(), rt.cpu().numpy()
+
+    ws_cold, ws_warm = ops.Workspace(dev, N, 0), ops.Workspace(dev, N, 0)
+    ws_cold.set_option("cold_start", 1)
+    c1, c2 = run(ws_cold), run(ws_cold)
+    assert c1[0] == c2[0] and np.array_equal(c1[1], c2[1]) and np.array_equal(c1[2], c2[2])
+    w1 = run(ws_warm)                      # first call on a fresh workspace: cold by itself
+    w2 = run(ws_warm)                      # warm: the first call's trajectory is the guess
+    ws_warm.reset_warm()
+    w3 = run(ws_warm)                      # the guess forgotten again
+    assert np.array_equal(w3[1], w1[1]) and w3[0] == w1[0]
+    for it, wg, rg in (c1, w1, w2, w3):
+        assert it == it_o, (it, it_o)
+        rel, small = rel_pi(wg, wo)
+        assert rel <= REL and small <= 1e-7
+        np.testing.assert_allclose(rg, ro, rtol=1e-6, atol=1e-6)
+
+
 def test_calls_with_out_do_not_disturb_an_accumulate_sequence(gpu, oracle):
     """ABI 3: a call WITH `out` (an evaluation batch, a small-loss selection, per_sample_ce) keeps its records
     apart, so it may sit between the batches of an accumulate-mode epoch on the same workspace: the epoch's
