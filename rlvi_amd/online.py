@@ -56,13 +56,13 @@ def rlvi_sample_weight(X, coef=None, intercept=0.0, tol=1e-3, maxiter=100):
         return w.cpu().numpy()
     Xh = np.ascontiguousarray(X, dtype=np.float64)
     d = Xh.shape[1] if Xh.ndim == 2 else 1
-    h_in, h_out = _STAGE.get(dev, "online", (n * d + d, n))
+    h_in, h_out, d_in, d_out = _STAGE.get(dev, "online", (n * d + d, n), device_side=True)
     if not first:
         h_in.numpy()[:n * d] = Xh.reshape(-1)
         h_in.numpy()[n * d:] = np.ascontiguousarray(coef, dtype=np.float64).ravel()
-    d_in = h_in.to(dev, non_blocking=True) if not first else torch.empty(n * d + d, dtype=torch.float64, device=dev)
-    d_out, _, _ = ops.sample_weight_online(d_in[:n * d].view(n, d), d_in[n * d:], float(intercept), first=first,
-                                           tol=tol, maxiter=maxiter)
+        d_in.copy_(h_in, non_blocking=True)
+    ops.sample_weight_online(d_in[:n * d].view(n, d), d_in[n * d:], float(intercept), first=first,
+                             tol=tol, maxiter=maxiter, out=d_out)
     h_out.copy_(d_out, non_blocking=True)
     torch.cuda.current_stream(dev).synchronize()
     return h_out.numpy()[:n].copy()

@@ -37,15 +37,19 @@ class _Staging:
         self._sets = collections.OrderedDict()
         self._cap = cap
 
-    def get(self, dev, tag, sizes, dtype=torch.float64):
+    def get(self, dev, tag, sizes, dtype=torch.float64, device_side=False):
+        """(h_0, h_1, ...) pinned host buffers of the given lengths; device_side: followed by device buffers of the
+        same lengths (kept with the set: a call then allocates nothing)."""
         import threading
-        key = (threading.get_ident(), dev.index, tag, tuple(int(x) for x in sizes), dtype)
+        key = (threading.get_ident(), dev.index, tag, tuple(int(x) for x in sizes), dtype, device_side)
         with self._lock:
             st = self._sets.get(key)
             if st is not None:
                 self._sets.move_to_end(key)
                 return st
         st = tuple(torch.empty(max(int(x), 1), dtype=dtype).pin_memory() for x in sizes)
+        if device_side:
+            st = st + tuple(torch.empty(max(int(x), 1), dtype=dtype, device=dev) for x in sizes)
         with self._lock:
             self._sets[key] = st
             while len(self._sets) > self._cap:
@@ -125,11 +129,10 @@ def linear_regression(X, y, maxiter=100, tol=1e-3, return_info=False):
     n, d = Xh.shape
     ws = ops.workspace(dev, n, 0)
     if n > 0 and d > 0 and ops.linear_regression_check(n, d):
-        h_in, h_out = _STAGE.get(dev, "linreg", (n * d + n, d + n + 2))
+        h_in, h_out, d_in, d_out = _STAGE.get(dev, "linreg", (n * d + n, d + n + 2), device_side=True)
         h_in.numpy()[:n * d] = Xh.reshape(-1)
         h_in.numpy()[n * d:] = yh
-        d_in = h_in.to(dev, non_blocking=True)
-        d_out = torch.empty(d + n + 2, dtype=torch.float64, device=dev)
+        d_in.copy_(h_in, non_blocking=True)
         info = d_out[d + n:].view(torch.int32)              # 4 x int32 behind theta and the weights
         ops.linear_regression(d_in[:n * d].view(n, d), d_in[n * d:], maxiter=maxiter, tol=tol,
                               theta=d_out[:d], weights=d_out[d:d + n], info=info, ws=ws)
