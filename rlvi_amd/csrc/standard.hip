@@ -504,9 +504,12 @@ __global__ __launch_bounds__(SL_THREADS) void linreg_rlvi_kernel(
             double sse = 0.0, sum = 0.0;
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const bool v = tid + j * SL_THREADS < n;
-                double nw = e[j] / (ratio + e[j]);                 // rlvi.py:15
-                nw = v ? nw : 0.0;
+                // rlvi.py:15.  (A reciprocal + Newton + correction in place of the IEEE division, with a wave-uniform
+                // branch for operands near the ends of the exponent range, and the stop test on the squares, were
+                // measured: 0.70 us per iteration against 0.57 -- every ballot-and-branch is a scalar round trip on
+                // a wave that issues alone.)
+                double nw = e[j] / (ratio + e[j]);
+                nw = (tid + j * SL_THREADS < n) ? nw : 0.0;
                 const double dd = nw - w[j];
                 sse = __builtin_fma(dd, dd, sse);
                 sum += nw;
@@ -626,10 +629,8 @@ __global__ __launch_bounds__(SL_THREADS) void online_weight_kernel(
         double sse = 0.0, sum = 0.0;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const bool v = tid + j * SL_THREADS < n;
-            const double t = ratio * e[j];                          // main.py:52
-            double nw = t / (1.0 + t);
-            nw = v ? nw : 0.0;
+            const double t = ratio * e[j];                          // main.py:52 (a sample past n: e = 0, update 0)
+            const double nw = t / (1.0 + t);
             const double dd = nw - w[j];
             sse = __builtin_fma(dd, dd, sse);
             sum += nw;
