@@ -660,6 +660,163 @@ __global__ __launch_bounds__(WPB *WAVE, RLVI_MSTEP_WAVE_MINW) void mstep_wave_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16 rows of an ODD number of elements (C = 101: 202-byte rows, every other row starts in the
+// middle of a 32-bit word), at least 32 768 of them (round 4; the round-3 verdict's item 4b).  The general wave tile
+// reads such a row one 2-byte element per LDS instruction (27.5 us at 65 536 x 101, so the launcher sent the shape
+// to the register-row kernel: 14.3 us).  Here the tile is the same flat 16-B/lane stream into LDS, but a lane owns a
+// CONTIGUOUS segment of its row -- four lanes per row, L = ceil(C / 4) elements each -- and reads it as 32-bit words
+// from the word its first element lies in; v_alignbit re-aligns the words of an odd start, a shift and a mask widen the
+// two halves.  The gradient goes back in place as bf16 halves (v_cvt_pk_bf16_f32 per pair, one 16-bit LDS store per
+// element: a word of the tile may belong to two lanes, or two rows) and leaves as flat 16-B stores.
+// ---------------------------------------------------------------------------------------
+template <int KW, int WPB>
+__global__ __launch_bounds__(WPB *WAVE, 4) void mstep_bf16w_kernel(
+    const uint16_t *__restrict__ logits, const int64_t *__restrict__ labels, const int64_t *__restrict__ idx,
+    const float *__restrict__ weights, float *__restrict__ residuals, int64_t N, int64_t nfull, int C,
+    float inv_scale, uint16_t *__restrict__ grad, double *__restrict__ part, int32_t *__restrict__ status,
+    int accum, double inv_rows100) {
+    constexpr int R = 16, G = 4, NI = 4;                          // 16 rows x <= 128 elements x 2 B <= 4 KiB
+    constexpr int WTILE = NI * 1024 + 64;                         // (+ a pad: the word past a segment's end, dummy stores)
+    constexpr int NE = 2 * KW;                                    // element slots of a lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int g = lane & (G - 1), sub = lane / G;
+    char *wtile = smem + (size_t)wave * WTILE;
+    vu4 *tile16 = reinterpret_cast<vu4 *>(wtile);
+    const int nchunk = 2 * C;                                     // 16-byte chunks of a tile (16 rows x 2 C bytes)
+    const int L = (C + 3) >> 2;
+    const int e0 = g * L;
+    const int cnt = C - e0 < L ? (C - e0 > 0 ? C - e0 : 0) : L;   // elements of this lane's segment
+    const int E0 = sub * C + e0;                                  // first element, counted in the tile
+    const unsigned shift = (unsigned)(E0 & 1) * 16u;              // odd start: the segment begins in a word's high half
+    const int W0 = E0 >> 1;
+    const int64_t *idxp = idx != nullptr ? idx : labels;
+    const unsigned sub8 = (unsigned)sub * 8u;
+    const int64_t tstride = (int64_t)gridDim.x * WPB;
+    float acc = 0.0f, hits = 0.0f;
+    bool bad = false;
+    for (int64_t t = (int64_t)blockIdx.x * WPB + wave; t < nfull; t += tstride) {
+        const int64_t row_base = t * R;
+        const char *src = reinterpret_cast<const char *>(logits + row_base * C);
+        int64_t y64 = *reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(labels + row_base) + sub8);
+        int64_t ix = *reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(idxp + row_base) + sub8);
+        vu4 stg[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int c = i * WAVE + lane;
+            c = c < nchunk ? c : nchunk - 1;                      // past the tile: re-read its last chunk
+            stg[i] = __builtin_nontemporal_load(reinterpret_cast<const vu4 *>(src + (size_t)c * 16));
+        }
+        bool okrow = true;
+        ix = idx != nullptr ? ix : row_base + sub;
+        if (y64 < 0 || y64 >= C) { y64 = 0; okrow = false; }
+        if (ix < 0 || ix >= N) { ix = 0; okrow = false; }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (i * WAVE + lane < nchunk) tile16[i * WAVE + lane] = stg[i];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(y64), "+v"(ix) : : "memory");
+        float pi = weights != nullptr ? weights[ix] : 1.0f;         // behind the tile (see mstep_wave_kernel)
+        bad = bad || !okrow;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- B: the segment as words, re-aligned, widened
+        const int y = (int)y64;
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(wtile);
+        const uint16_t *h16 = reinterpret_cast<const uint16_t *>(wtile);
+        const float zy = bf16_to_f32(h16[sub * C + y]);
+        uint32_t w[KW + 1];
+#pragma unroll
+        for (int k = 0; k <= KW; ++k) w[k] = w32[W0 + k];
+        float v[NE];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const uint32_t x = __builtin_amdgcn_alignbit(w[k + 1], w[k], shift);      // elements 2k, 2k + 1
+            v[2 * k] = __uint_as_float(x << 16);
+            v[2 * k + 1] = __uint_as_float(x & 0xFFFF0000u);
+        }
+        const float NEG_INF = -__builtin_inff();
+        float m = NEG_INF;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            v[j] = j < cnt ? v[j] : NEG_INF;
+            m = __builtin_fmaxf(m, v[j]);
+        }
+        m = group_allreduce<G>(m, FMaxF());
+        const bool hit0 = zy == m;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            v[j] = mexp(v[j] - m);                                // a slot past the segment: exp(-inf) = 0
+            s += v[j];
+        }
+        s = group_sum<G>(s);
+        const float li = __builtin_amdgcn_logf(s) * 0.69314718055994530942f - (zy - m);
+        pi = okrow ? pi : 0.0f;
+        // top-1: the label is a hit when it is the FIRST column that attains the row maximum; two exact maxima put
+        // at least 2.0 into the sum, so the exact check (the words are still in registers) runs only for waves
+        // that hold such a row
+        bool hit = hit0;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit0 && s >= 2.0f) != 0, 0)) {
+            int earlier = 0;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const uint32_t x = __builtin_amdgcn_alignbit(w[k + 1], w[k], shift);
+                const float z0 = __uint_as_float(x << 16), z1 = __uint_as_float(x & 0xFFFF0000u);
+                earlier += (2 * k < cnt && z0 == m && e0 + 2 * k < y) ? 1 : 0;
+                earlier += (2 * k + 1 < cnt && z1 == m && e0 + 2 * k + 1 < y) ? 1 : 0;
+            }
+            hit = hit0 && group_allreduce<G>(earlier, FAdd()) == 0;
+        }
+        if (grad != nullptr) {
+            const float gs = pi * inv_scale;
+            const float inv_s = gs * __builtin_amdgcn_rcpf(s);
+            const int jy = y - e0;                                // the label's slot, if it lies in this segment
+            uint16_t *o16 = reinterpret_cast<uint16_t *>(wtile);
+            const int dummy = NI * 512 + (lane & 15);             // a halfword of the pad, per lane
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                float o0 = v[2 * k] * inv_s, o1 = v[2 * k + 1] * inv_s;
+                o0 = 2 * k == jy ? o0 - gs : o0;
+                o1 = 2 * k + 1 == jy ? o1 - gs : o1;
+                const uint32_t pk = f32x2_to_bf16x2(o0, o1);
+                o16[2 * k < cnt ? E0 + 2 * k : dummy] = (uint16_t)(pk & 0xFFFFu);
+                o16[2 * k + 1 < cnt ? E0 + 2 * k + 1 : dummy] = (uint16_t)(pk >> 16);
+            }
+        }
+        if (g == 0 && okrow && residuals != nullptr) residuals[ix] = li;
+        acc += okrow ? li * pi : 0.0f;
+        hits += (hit && okrow) ? 1.0f : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- C: flat store of the gradient tile
+        if (grad != nullptr) {
+            char *gdst = reinterpret_cast<char *>(grad + row_base * C);
+            vu4 st[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) st[i] = tile16[(i * WAVE + lane < nchunk) ? i * WAVE + lane : 0];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (i * WAVE + lane < nchunk)
+                    __builtin_nontemporal_store(st[i], reinterpret_cast<vu4 *>(gdst + (size_t)(i * WAVE + lane) * 16));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    double a = wave_sum((double)(g == 0 ? acc : 0.0f));
+    double h = wave_sum((double)(g == 0 ? hits : 0.0f));
+    __shared__ double sh[2 * WPB];
+    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = h; }
+    if (bad) atomicOr(status, RLVI_ST_RANGE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, th = 0.0;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
+        write_partial(part, ta, th, inv_scale, inv_rows100, accum);
+    }
+}
+
 // Hold of the reads-then-writes form for a launch that reads `bytes` of logits, in ticks of 10 ns: the time
 // its reads need at the read-only rate.  Fitted to the best hold of a sweep per shape (tools/sweep_hold.sh:
 // 13.6 MB bf16 -> 2.4 us, 16.8 MB -> 2.9, 19.7 MB -> 3.4, 26.2 MB -> 4.3, 33.5 MB -> 5.2): 0.68 us of ramp-up
@@ -910,6 +1067,46 @@ static int mstep_entry(const T *logits, int64_t ld, const int64_t *labels, const
     };
     constexpr int VMAX = 16 / (int)sizeof(T);
     const int Ci = (int)C;
+    if constexpr (sizeof(T) == 2) {
+        // bf16 rows of an odd number of elements (single 2-byte elements in the general forms), at least 32 768 of
+        // them, dense, 16-byte aligned: the
+        // word-wise wave tile (mstep_bf16w_kernel); the B mod 16 trailing rows go to the register-row kernel
+        if (((C & 1) != 0 || tune_get("RLVI_MSTEP_BF16W", 1) == 2) && C >= 9 && C <= 127 && B >= 16 * 2048 && ld == C && (grad == nullptr || ldg == C) &&
+            ((uintptr_t)logits % 16) == 0 && ((uintptr_t)grad % 16) == 0 && tune_get("RLVI_MSTEP_BF16W", 1) &&
+            tune_get("RLVI_MSTEP_FORM", -1) != 0 && tune_get("RLVI_MSTEP_G", 0) == 0) {
+            constexpr int WPB = 4;
+            char *base = static_cast<char *>(ws);
+            double *part = reinterpret_cast<double *>(base + (out == nullptr ? WS_PART_OFF : WS_PART2_OFF));
+            int32_t *status = reinterpret_cast<int32_t *>(base);
+            const int accum = out == nullptr ? 1 : 0;
+            const double inv_rows100 = 100.0 / (double)B;
+            const int64_t nfull = B / 16;
+            int64_t nb = (nfull + WPB - 1) / WPB;
+            int64_t cap = ((int64_t)tune_get("RLVI_MSTEP_WPC", 16) * device_info().cus + WPB - 1) / WPB;
+            if (cap > MSTEP_MAX_BLOCKS) cap = MSTEP_MAX_BLOCKS;
+            if (nb > cap) nb = cap;
+            const size_t lds = (size_t)WPB * (4 * 1024 + 64);
+            const int L = (Ci + 3) / 4;
+            const int kw = (L + 1) / 2;
+            int rc;
+            ws_note_mstep(ws, 4);
+#define RLVI_BW(KW_)                                                                                       \
+    rc = launch(mstep_bf16w_kernel<KW_, WPB>, dim3((unsigned)nb), dim3(WPB * WAVE), lds, st, logits, labels, idx, \
+                weights, residuals, N, nfull, Ci, inv_scale, grad, part, status, accum, inv_rows100)
+            if (kw <= 8) RLVI_BW(8);
+            else if (kw <= 13) RLVI_BW(13);
+            else RLVI_BW(16);
+#undef RLVI_BW
+            const int64_t done = nfull * 16;
+            if (rc == 0 && done < B)
+                rc = launch(mstep_kernel<T, 1, 16, 8>, dim3(1), dim3(MSTEP_THREADS), 0, st, logits + done * ld, ld,
+                            labels + done, idx != nullptr ? idx + done : idx, weights, residuals, N, B - done, Ci,
+                            (Ci + 15) / 16, inv_scale, grad != nullptr ? grad + done * ldg : grad, ldg, part, status, 1,
+                            inv_rows100, done);
+            if (rc != 0 || out == nullptr) return rc;
+            return launch(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 1.0, out, 1);
+        }
+    }
     if constexpr (VMAX == 8) {
         if (ok(8))
             return dispatch_gk<T, 8>(logits, ld, labels, idx, weights, residuals, N, B, Ci,

@@ -144,7 +144,10 @@ def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     (70003, 7, "f32"),       # single elements, one lane per row
     (1024, 101, "bf16"),     # cfg5: 32 lanes per row, register rows
     (8195, 101, "bf16"),     # 16 lanes per row, register rows (a 4-row tile is not a multiple of 16 bytes)
-    (70003, 101, "bf16"),
+    (70003, 101, "bf16"),    # odd bf16 rows from 32 768 rows on: the word-wise wave tile (mstep_bf16w_kernel) + 3 trailing rows
+    (32768, 33, "bf16"),     # ... eight words per lane, no trailing rows
+    (40000, 127, "bf16"),    # ... sixteen words per lane, the longest row it takes
+    (36005, 9, "bf16"),      # ... the shortest: lanes 3 of a row's group hold nothing
     (1029, 104, "bf16"),     # eight lanes x two 8-element vectors, register rows
     (20005, 104, "bf16"),    # four lanes per row, wave tiles
     (3000, 200, "bf16"),
