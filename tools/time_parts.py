@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=0, help="E-step / threshold vector leng
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--tag", default="")
+ap.add_argument("--seq-idx", action="store_true", help="sample indices in order instead of a permutation (lab: what the random gather / scatter costs)")
 ap.add_argument("--tune", action="append", default=[], help="NAME=VALUE knob (rlvi_tune_set); repeatable")
 ap.add_argument("--sweep", default="", help="NAME=v1,v2,...: time the leg once per value")
 a = ap.parse_args()
@@ -26,6 +27,8 @@ dev = torch.device("cuda:0")
 B, C = a.rows, a.classes
 N = a.n or B
 d0, labels, idx, logits, grads, weights, residuals = bench.make_inputs(torch, dev, B, C, B, 0)
+if a.seq_idx:
+    idx = torch.arange(B, device=dev, dtype=torch.int64)
 if a.dtype == "bf16":
     logits = [z.to(torch.bfloat16) for z in logits]
     grads = [g.to(torch.bfloat16) for g in grads]
