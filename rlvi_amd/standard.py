@@ -148,12 +148,19 @@ def linear_regression(X, y, maxiter=100, tol=1e-3, return_info=False):
     else:
         Xd, yd = torch.from_numpy(Xh).to(dev), torch.from_numpy(yh).to(dev)
     theta, w, outer = _linear_regression_host_loop(Xd, yd, maxiter, tol)
+    th = theta.cpu().numpy()
+    if not np.isfinite(th).all():
+        # the reference's error behaviour: scipy's lstsq (rlvi.py:71,80; check_finite) raises this ValueError as
+        # soon as a non-finite number reaches it -- in X or y, or in the weights of an exactly interpolating fit
+        # (variance 0 -> 0/0 losses); here the NaN has run through to theta instead, which happens in no other case
+        ws.clear_status()
+        raise ValueError("array must not contain infs or NaNs")
     # a cooperating launch that could not run, a fixed point that did not converge: never silent
     # (RLVI_ST_SINGULAR is information: the minimum-norm solution was returned, as lstsq does)
     ws.raise_on_status("linear_regression", mask=_lib.ST_TIMEOUT | _lib.ST_NOCONV)
     if return_info:
-        return theta.cpu().numpy(), w.cpu().numpy(), outer
-    return theta.cpu().numpy()
+        return th, w.cpu().numpy(), outer
+    return th
 
 
 def _sklearn_log_reg(X_host, y_host, X_dev, w_dev, reg_coeff=1e2):

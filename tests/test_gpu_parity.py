@@ -1251,6 +1251,32 @@ def test_linear_regression_in_one_launch_vs_oracle(n, d, gpu, oracle):
     assert dev_status(ops, dev) == 0
 
 
+def test_linear_regression_random_shapes_vs_oracle(gpu, oracle):
+    """Forty seeded random shapes (1 <= d <= 31, n up to 4096), contaminations (0 ... 45 %), tail weights and target
+    scales through the one launch against the oracle -- well-posed ones: at least d + 8 clean samples (nearer to
+    interpolation the weighted system loses its numerical rank and the outcome hangs on the solver's singular-value
+    cutoff: tools/lab/fuzz_linreg.py lists those)."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 40:
+        d = int(rng.integers(1, 32))
+        eps = float(rng.choice([0.0, 0.05, 0.3, 0.45]))
+        n = int(rng.integers(int((d + 8) / (1.0 - eps)) + 1, 4097))
+        X, y = synth.linreg_data(n, d, eps=eps, nu=float(rng.choice([1.0, 2.5, 10.0])), seed=7000 + done)
+        y = y * float(rng.choice([1.0, 1.0, 1e-6, 1e6]))
+        done += 1
+        th_o, w_o, outer_o = oracle.linear_regression(X, y, trace=True)
+        theta, w, info = ops.linear_regression(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev))
+        torch.cuda.synchronize()
+        info = info.cpu().numpy()
+        assert info[3] == 0 and info[0] == outer_o, (n, d, eps, info, outer_o)
+        np.testing.assert_allclose(theta.cpu().numpy(), th_o, rtol=1e-7, atol=1e-10 * float(np.abs(th_o).max()),
+                                   err_msg=f"n={n} d={d} eps={eps}")
+        np.testing.assert_allclose(w.cpu().numpy(), w_o, rtol=1e-6, atol=1e-9, err_msg=f"n={n} d={d} eps={eps}")
+    assert dev_status(ops, dev) == 0
+
+
 def test_linear_regression_one_launch_limits_and_fallback(golden, gpu, oracle):
     """Beyond n = 4096 or d = 31 the C entry refuses (RLVI_E_LIMIT) and the mirror takes the general path; a
     rank-deficient design ends the launch with info[3] = 1 WITHOUT writing theta, and the mirror then returns
@@ -1275,11 +1301,13 @@ def test_linear_regression_one_launch_limits_and_fallback(golden, gpu, oracle):
     np.testing.assert_allclose(standard.linear_regression(Xr, yr), g["linreg_rankdef/theta"], rtol=1e-7, atol=1e-9)
     assert ws.status() & 8                    # RLVI_ST_SINGULAR: information, raised by the general path
     ws.clear_status()
-    # non-finite data: the launch says "fallback", the general path returns NaN -- never a silent number
+    # non-finite data: the launch says "fallback", the NaN runs through the general path, and the mirror raises what
+    # the reference raises there (scipy lstsq's check_finite, rlvi.py:71) -- never a silent number
     Xn = X[:, :5].copy()
     Xn[3, 2] = np.nan
-    assert np.isnan(standard.linear_regression(Xn, y)).all()
-    ws.clear_status()
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        standard.linear_regression(Xn, y)
+    assert ws.status() == 0
 
 
 @pytest.mark.parametrize("n,d", [(256, 60), (100, 3), (200, 561), (17, 130), (1000, 32), (4096, 20), (1, 7)])
