@@ -305,6 +305,98 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Long rows (more than 512 vectors: C > 2048 fp32 / 4096 bf16 aligned, C > 512 in single elements -- an odd
+// ImageNet-21k head, a padded pitch): a row does not fit a wave's registers, so ONE WAVE walks its row three times
+// from global memory (the second and third pass are L2 hits): maximum -- sum of exponentials, label logit and the
+// ties in front of the label -- gradient.  Same arithmetic and the same records as the register-row kernel.
+template <typename T, int V>
+__global__ __launch_bounds__(MSTEP_THREADS) void mstep_longrow_kernel(
+    const T *__restrict__ logits, int64_t ld, const int64_t *__restrict__ labels,
+    const int64_t *__restrict__ idx, const float *__restrict__ weights,
+    float *__restrict__ residuals, int64_t N, int64_t B, int C, float inv_scale,
+    T *__restrict__ grad, int64_t ldg, double *__restrict__ part, int32_t *__restrict__ status,
+    int accum, double inv_rows100) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    float acc = 0.0f, hits = 0.0f;
+    bool bad = false;
+    const int nv = C / V;                                         // (V divides C)
+    const int64_t stride = (int64_t)gridDim.x * MSTEP_WAVES;
+    for (int64_t row = (int64_t)blockIdx.x * MSTEP_WAVES + wave; row < B; row += stride) {
+        const T *zrow = logits + row * ld;
+        int64_t y64 = labels[row];
+        int64_t ix = idx != nullptr ? idx[row] : row;
+        bool row_ok = true;
+        if (y64 < 0 || y64 >= C) { y64 = 0; bad = true; row_ok = false; }
+        if (ix < 0 || ix >= N) { ix = 0; bad = true; row_ok = false; }
+        const int y = (int)y64;
+        const float pi = weights != nullptr ? weights[ix] : 1.0f;
+        float zy;
+        {
+            float t[1];
+            VecIO<T, 1>::load(zrow + y, t);
+            zy = t[0];
+        }
+        float m = -__builtin_inff();
+        for (int k = lane; k < nv; k += WAVE) {
+            float v[V];
+            VecIO<T, V>::load(zrow + (size_t)k * V, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) m = fmaxf(m, v[j]);
+        }
+        m = group_max<WAVE>(m);
+        float s = 0.0f;
+        int earlier = 0;
+        for (int k = lane; k < nv; k += WAVE) {
+            float v[V];
+            VecIO<T, V>::load(zrow + (size_t)k * V, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s += mexp(v[j] - m);
+                earlier += (v[j] == m && k * V + j < y) ? 1 : 0;
+            }
+        }
+        s = group_sum<WAVE>(s);
+        earlier = group_allreduce<WAVE>(earlier, FAdd());
+        const float li = logf(s) - (zy - m);
+        if (grad != nullptr) {
+            const float gs = row_ok ? pi * inv_scale : 0.0f;
+            const float inv_s = gs / s;
+            T *grow = grad + row * ldg;
+            for (int k = lane; k < nv; k += WAVE) {
+                float v[V], o[V];
+                VecIO<T, V>::load(zrow + (size_t)k * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float p = mexp(v[j] - m) * inv_s;
+                    if (k * V + j == y) p -= gs;
+                    o[j] = p;
+                }
+                VecIO<T, V>::store_stream(grow + (size_t)k * V, o);
+            }
+        }
+        const bool hit = zy == m && earlier == 0;
+        if (lane == 0 && row_ok) {
+            if (residuals != nullptr) residuals[ix] = li;
+            acc += li * pi;
+            hits += hit ? 1.0f : 0.0f;
+        }
+    }
+    double a = wave_sum((double)acc);
+    double h = wave_sum((double)hits);
+    __shared__ double sh[2 * MSTEP_WAVES];
+    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = h; }
+    if (bad) atomicOr(status, RLVI_ST_RANGE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, th = 0.0;
+#pragma unroll
+        for (int w = 0; w < MSTEP_WAVES; ++w) { ta += sh[2 * w]; th += sh[2 * w + 1]; }
+        write_partial(part, ta, th, inv_scale, inv_rows100, accum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Wave-tile form (dense rows): every WAVE streams its own tiles of R = 64/G rows through its own
 // slice of LDS -- no workgroup barrier anywhere, and the hot loop is straight-line code:
 //   A  label / index (asm loads the compiler does not count), then the tile global -> LDS by
@@ -1022,7 +1114,19 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
     // 3.65 -> 3.3 us, 4096 x 100 4.4 -> 4.05, 1024 x 101 3.35 -> 3.1; from 1024 waves on the wider tile wins)
     if (!force_g && gsel < 64 && (nv + gsel - 1) / gsel >= 2 && (B * gsel + 63) / 64 < 1024) gsel *= 2;
     const int k = (nv + gsel - 1) / gsel;
-    if (k > 8) return RLVI_E_LIMIT;
+    if (k > 8) {
+        // more than 512 vectors per row: one wave per row, three passes (mstep_longrow_kernel)
+        char *base = static_cast<char *>(ws);
+        double *part = reinterpret_cast<double *>(base + (out == nullptr ? WS_PART_OFF : WS_PART2_OFF));
+        int64_t nb = (B + MSTEP_WAVES - 1) / MSTEP_WAVES;
+        if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
+        ws_note_mstep(ws, 5);
+        const int rc = launch(mstep_longrow_kernel<T, V>, dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st, logits, ld,
+                              labels, idx, weights, residuals, N, B, C, inv_scale, grad, ldg, part,
+                              reinterpret_cast<int32_t *>(base), out == nullptr ? 1 : 0, 100.0 / (double)B);
+        if (rc != 0 || out == nullptr) return rc;
+        return launch(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 1.0, out, 1);
+    }
     switch (gsel) {
         case 1:
             if (k <= 1) RLVI_CASE(1, 1);

@@ -151,6 +151,11 @@ def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     (1029, 104, "bf16"),     # eight lanes x two 8-element vectors, register rows
     (20005, 104, "bf16"),    # four lanes per row, wave tiles
     (3000, 200, "bf16"),
+    (301, 3000, "f32"),      # long rows (more than 512 vectors): one wave per row, three passes
+    (70, 21841, "f32"),      # ... an odd ImageNet-21k head, single elements
+    (1030, 513, "f32"),      # ... the shortest odd row that takes it
+    (130, 4104, "bf16"),     # ... bf16, 8-element vectors
+    (257, 1001, "bf16"),     # ... bf16, single elements
 ])
 def test_mstep_dispatch_by_launch_size_vs_oracle(B, C, dtype, gpu, oracle):
     """The launcher picks lanes per row and kernel form by the SIZE of the launch (mstep.hip dispatch_gk /
