@@ -26,7 +26,12 @@ with torch.cuda.stream(side):
                                       B, B, C, 1.0 / B, ops._ptr(grads[k]), C, None, ws.ptr, ops._stream_ptr())
         _lib.check(rc, "mstep")
 
+    ones = torch.ones_like(weights)
+    zero_ix = torch.zeros_like(idx)
     for name, ix, w, r in (("gather + scatter, permuted", idx, weights, residuals),
+                           ("in-order gather of all-ones weights, no scatter", None, ones, None),
+                           ("in-order gather, no scatter", None, weights, None),
+                           ("every row gathers weights[0], no scatter", zero_ix, weights, None),
                            ("permuted gather, no scatter", idx, weights, None),
                            ("no gather (pi = 1), in-order scatter", None, None, residuals),
                            ("neither", None, None, None),
