@@ -252,6 +252,22 @@ int rlvi_truncate_f32(float *weights, int64_t N, const float *thr, uint8_t *mask
 int rlvi_select_smallest_f32(const float *loss, int64_t n, int64_t k, float *mask_w, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * precision@k.  Replaces accuracy(logit, target, topk) of deep-learning/utils.py:65-79 (softmax :67, torch.topk
+ * :70, eq :72, the per-k counts :76-77): hits[j] = number of rows whose label is among the ks[j]
+ * largest logits of its row, j < nk <= 8.  train_rlvi keeps only precision@1 (train_rlvi.py:85), which the
+ * M-step kernel delivers on the side; this is the stand-alone form.  One pass, no softmax, no sort: the label's
+ * rank is the count of columns ahead of it; equal values rank in column order (torch.topk's order among equal
+ * values, and logits that differ but whose fp32 softmax values coincide, are implementation details of the
+ * reference: unpinned).  A label outside [0, C) is never a hit (:72).
+ *   ks     HOST array of nk values, each in [1, C] (RLVI_E_SHAPE beyond: torch.topk raises there)
+ *   hits   DEVICE int32 [nk], zeroed by the call; precision@k = 100 * hits / B
+ * ------------------------------------------------------------------------------------- */
+int rlvi_topk_hits_f32(const float *logits, int64_t ld, const int64_t *labels, int64_t B, int64_t C,
+                       const int32_t *ks, int nk, int32_t *hits, void *stream);
+int rlvi_topk_hits_bf16(const uint16_t *logits, int64_t ld, const int64_t *labels, int64_t B, int64_t C,
+                        const int32_t *ks, int nk, int32_t *hits, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * In-batch fused E+M (online order, online-learning/main.py:296-299 applied to a logit block):
  * per-sample NLL -> E-step on THIS batch (deep variant, pi_in only feeds the first error)
  * -> weighted loss and gradient with the NEW pi.  Composition of a1, a7, a4, a5 -- as ONE launch for fp32 dense

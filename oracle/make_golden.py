@@ -465,7 +465,34 @@ def gen_g9(ref):
     save("g9_top1_ties", **out)
 
 
-GROUPS = {"g9": gen_g9, "g7": gen_g7, "g8": gen_g8, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
+def gen_g10(ref):
+    """precision@k: the reference's accuracy(logit, target, topk=(1, 5)) (deep-learning/utils.py:65-79: softmax ->
+    topk -> eq) on seeded logits WITHOUT ties (continuous values; the order topk gives equal values is an
+    implementation detail), shapes incl. C = 5 (k = C) and a ragged batch; per-row rank of the label beside it."""
+    import torch
+    sys.path.insert(0, os.path.join(ref, "deep-learning"))
+    import utils as ref_utils
+    rng = np.random.default_rng(10)
+    out, keys = {}, []
+    for B, C in ((32, 10), (128, 100), (777, 101), (64, 5), (40, 1000)):
+        z = (3.0 * rng.standard_normal((B, C))).astype(np.float32)
+        labels = rng.integers(0, C, B).astype(np.int64)
+        clean = rng.random(B) < 0.4
+        z[np.nonzero(clean)[0], labels[clean]] += np.float32(4.0)
+        zt, yt = torch.from_numpy(z), torch.from_numpy(labels)
+        p1, p5 = ref_utils.accuracy(zt, yt, topk=(1, 5))
+        p3, = ref_utils.accuracy(zt, yt, topk=(3,))
+        key = f"B{B}_C{C}"
+        keys.append(key)
+        out[key + "/logits"] = z
+        out[key + "/labels"] = labels
+        out[key + "/prec"] = np.array([float(p1), float(p3), float(p5)], np.float64)
+        out[key + "/shape_of_result"] = np.array(p1.shape)
+    out["cases"] = np.array(keys)
+    save("g10_topk", **out)
+
+
+GROUPS = {"g10": gen_g10, "g9": gen_g9, "g7": gen_g7, "g8": gen_g8, "g12": gen_g1_g2, "g3": gen_g3, "g4": gen_g4, "g5": gen_g5, "g6": gen_g6}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

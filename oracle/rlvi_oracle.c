@@ -94,6 +94,31 @@ void rlvi_oracle_nll_rows_f32(const float *logits, int64_t ld,
 }
 
 /* ------------------------------------------------------------------------- *
+ * precision@k: accuracy(logit, target, topk) of deep-learning/utils.py:65-79.
+ * The reference ranks the SOFTMAX values with torch.topk (:70) and counts the
+ * rows whose label is among the first k (:72, :76-77).  Restated on the logits:
+ * rank_i = #{c : z_ic > z_iy} + #{c < y : z_ic == z_iy} (equal values in column
+ * order; which of several equal values topk lists first is an implementation
+ * detail of the reference, and so are logits that differ but whose fp32 softmax
+ * values coincide -- unpinned, as for top-1 in G9's note), hit@k = rank_i < k.
+ * A label outside [0, C) matches no prediction (:72): never a hit.
+ * ------------------------------------------------------------------------- */
+void rlvi_oracle_label_rank_f32(const float *logits, int64_t ld,
+                                const int64_t *labels, int64_t B, int64_t C,
+                                int32_t *rank) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < B; ++i) {
+        const float *z = logits + i * ld;
+        const int64_t y = labels[i];
+        if (y < 0 || y >= C) { rank[i] = (int32_t)C; continue; }
+        int32_t r = 0;
+        for (int64_t c = 0; c < C; ++c)
+            r += (z[c] > z[y] || (z[c] == z[y] && c < y)) ? 1 : 0;
+        rank[i] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------- *
  * a1..a6 fused: one mini-batch of the M-step with lagged pi.
  *   train_rlvi.py:85     prec = accuracy(logits, labels)      -> *prec1
  *   train_rlvi.py:89     loss_i = CE(logits_i, y_i)

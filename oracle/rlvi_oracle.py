@@ -52,6 +52,8 @@ def lib():
         L.rlvi_oracle_num_threads.restype = ctypes.c_int
         L.rlvi_oracle_set_threads.argtypes = [ctypes.c_int]
         L.rlvi_oracle_nll_rows_f32.argtypes = [_f32p, _i64, _i64p, _i64, _i64, _f32p, _i32p]
+        L.rlvi_oracle_label_rank_f32.argtypes = [_f32p, _i64, _i64p, _i64, _i64, _i32p]
+        L.rlvi_oracle_label_rank_f32.restype = None
         L.rlvi_oracle_mstep_f32.restype = ctypes.c_int
         L.rlvi_oracle_mstep_f32.argtypes = [_f32p, _i64, _i64p, _i64p, _f32p, _f32p, _i64,
                                             _i64, _i64, _i64, _f32p, _i64, _f32p, _f32p, _f32p]
@@ -105,6 +107,19 @@ def nll_rows(logits, labels):
     lib().rlvi_oracle_nll_rows_f32(_p(z, _f32p), C, _p(y, _i64p), B, C,
                                    _p(loss, _f32p), _p(hit, _i32p))
     return loss, hit
+
+
+def accuracy(logits, labels, topk=(1,)):
+    """deep-learning/utils.py:65-79: precision@k in per cent for every k of `topk` (list of floats); RuntimeError
+    when max(topk) exceeds the number of classes, as torch.topk raises there."""
+    z = _c(logits, np.float32)
+    y = _c(labels, np.int64)
+    B, C = z.shape
+    if max(topk) > C:
+        raise RuntimeError("selected index k out of range")
+    rank = np.empty(B, np.int32)
+    lib().rlvi_oracle_label_rank_f32(_p(z, _f32p), C, _p(y, _i64p), B, C, _p(rank, _i32p))
+    return [100.0 * float((rank < k).sum()) / B for k in topk]
 
 
 def mstep(logits, labels, idx, weights, residuals, scale_div=None, want_grad=True):

@@ -58,6 +58,8 @@ SIGNATURES = {
     "rlvi_threshold_truncate_f32": (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "rlvi_truncate_f32": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "rlvi_select_smallest_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "rlvi_topk_hits_f32": (_int, [_vp, _i64, _vp, _i64, _i64, ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp]),
+    "rlvi_topk_hits_bf16": (_int, [_vp, _i64, _vp, _i64, _i64, ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp]),
     "rlvi_fused_em_f32": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int,
                                  _vp, _i64, _vp, _vp, _vp, _vp]),
     "rlvi_update_weights_f64": (_int, [_vp, _i64, _f64, _int, _vp, _vp, _vp, _vp]),

@@ -568,6 +568,36 @@ def select_smallest(losses, k, out=None):
     return out
 
 
+def topk_hits(logits, labels, ks, out=None):
+    """Rows of the batch whose label is among the k largest logits, for every k of `ks` (at most 8): the counts
+    behind accuracy(logit, target, topk) of deep-learning/utils.py:65-79.  Returns a device int32 tensor [len(ks)]
+    (no host synchronisation here).  RuntimeError when a k exceeds the number of classes, as torch.topk raises."""
+    import ctypes
+    L = _lib.load()
+    _require_gpu(logits, labels)
+    if logits.dim() != 2:
+        raise ValueError("logits must be [B, C]")
+    B, C = logits.shape
+    ks = [int(k) for k in ks]
+    if not ks or len(ks) > 8:
+        raise ValueError("between one and eight values of k per call")
+    if max(ks) > C or min(ks) < 1:
+        raise RuntimeError("selected index k out of range")
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    if labels.dtype != torch.int64 or not labels.is_contiguous():
+        labels = labels.to(torch.int64).contiguous()
+    if out is None:
+        out = torch.empty(len(ks), dtype=torch.int32, device=logits.device)
+    karr = (ctypes.c_int32 * len(ks))(*ks)
+    fn = L.rlvi_topk_hits_f32 if logits.dtype == torch.float32 else L.rlvi_topk_hits_bf16
+    _lib.check(fn(_ptr(logits), logits.stride(0), _ptr(labels), B, C, karr, len(ks), _ptr(out), _stream_ptr()),
+               "rlvi_topk_hits")
+    return out
+
+
 def per_sample_ce(logits, labels, ws=None):
     """F.cross_entropy(logits, labels, reduction='none') by the streaming kernel (forward only)."""
     B = logits.shape[0]

@@ -102,6 +102,12 @@ def test_workspace_regions_options_and_shape_queries(lib):
     assert lib.rlvi_linear_regression_check(4097, 5) == -5 and lib.rlvi_linear_regression_check(100, 32) == -5
     assert lib.rlvi_linear_regression_check(0, 5) == -2
     assert lib.rlvi_stream_copy(None, None, 16, None) == -1
+    k15 = (ctypes.c_int32 * 2)(1, 5)
+    assert lib.rlvi_topk_hits_f32(None, 10, p, 4, 10, k15, 2, p, None) == -1
+    assert lib.rlvi_topk_hits_f32(p, 10, p, 4, 10, k15, 0, p, None) == -2
+    assert lib.rlvi_topk_hits_f32(p, 10, p, 4, 10, k15, 9, p, None) == -2
+    assert lib.rlvi_topk_hits_f32(p, 4, p, 4, 4, k15, 2, p, None) == -2            # k = 5 beyond C = 4: torch.topk raises
+    assert lib.rlvi_topk_hits_bf16(p, 10, p + 4, 4, 10, k15, 2, p, None) == -3     # labels not 8-byte aligned
     assert lib.rlvi_stream_copy(p, p + 8, 16, None) == -3 and lib.rlvi_stream_copy(p, p + 16, 24, None) == -3
 
 

@@ -2388,6 +2388,64 @@ def test_top1_on_tied_maxima_golden(key, dtype, golden, gpu):
     assert ops.workspace(dev).status() == 0
 
 
+@pytest.mark.parametrize("key", ["B32_C10", "B128_C100", "B777_C101", "B64_C5", "B40_C1000"])
+def test_precision_at_k_golden(key, golden, gpu):
+    """G10 (the reference's accuracy(logit, target, topk), utils.py:65-79, on tie-free rows) through the mirror
+    rlvi_amd.utils.accuracy: precision@1 / @5 (and @3) as the reference returned them, one-element fp32 device tensors
+    as the reference returns; bf16-rounded logits against the oracle on the rounded values; a padded pitch; k = C;
+    the RuntimeError beyond."""
+    torch, ops, dev = gpu
+    from oracle import rlvi_oracle
+    from rlvi_amd import utils
+    g = golden("g10_topk")
+    z, y = torch.from_numpy(g[key + "/logits"]).to(dev), torch.from_numpy(g[key + "/labels"]).to(dev)
+    B, C = z.shape
+    ks = (1, 3, 5)
+    res = utils.accuracy(z, y, topk=ks)
+    assert all(r.shape == (1,) and r.dtype == torch.float32 and r.is_cuda for r in res)
+    np.testing.assert_allclose([float(r) for r in res], g[key + "/prec"], rtol=1e-6, atol=1e-5)
+    p1, p5 = utils.accuracy(z, y, topk=(1, 5))
+    assert float(p1) == float(res[0]) and float(p5) == float(res[2])
+    # precision@1 is what the streaming kernel counts on the side
+    out = ops.evaluate_batch(z, y)
+    assert float(out[1]) == pytest.approx(float(p1), abs=1e-3)
+    # a padded pitch, and bf16 (ties appear once the values are rounded: the oracle's column-order rule)
+    zp = torch.zeros((B, C + 3), device=dev)
+    zp[:, :C] = z
+    assert torch.equal(ops.topk_hits(zp[:, :C], y, ks), ops.topk_hits(z, y, ks))
+    zb = z.to(torch.bfloat16)
+    want = rlvi_oracle.accuracy(zb.float().cpu().numpy(), g[key + "/labels"], topk=ks)
+    np.testing.assert_allclose([float(r) for r in utils.accuracy(zb, y, topk=ks)], want, rtol=1e-6, atol=1e-5)
+    # k = C counts every row with a valid label; beyond: what torch.topk raises
+    assert int(ops.topk_hits(z, y, (C,))[0]) == B
+    with pytest.raises(RuntimeError):
+        utils.accuracy(z, y, topk=(1, C + 1))
+    # a label outside [0, C) is never a hit (it matches no prediction, utils.py:72)
+    y2 = y.clone()
+    y2[0] = C + 7
+    y2[1] = -1
+    h = ops.topk_hits(z, y2, (C,))
+    assert int(h[0]) == B - 2
+
+
+def test_precision_at_k_random_shapes_vs_oracle(gpu, oracle):
+    """Thirty seeded shapes (1 ... 5000 rows, 1 ... 3000 classes, ties from quantised values included: the oracle's
+    column-order rule) against the oracle, every k of a random list."""
+    torch, ops, dev = gpu
+    rng = np.random.default_rng(10)
+    for trial in range(30):
+        B = int(np.exp(rng.uniform(0, np.log(5000))))
+        C = int(np.exp(rng.uniform(0, np.log(3000))))
+        z = (3.0 * rng.standard_normal((B, C))).astype(np.float32)
+        if trial % 3 == 0:
+            z = np.round(z * 2) / 2                                   # heavy ties
+        y = rng.integers(0, C, B).astype(np.int64)
+        ks = sorted({int(k) for k in rng.integers(1, C + 1, int(rng.integers(1, 9)))})
+        got = ops.topk_hits(torch.from_numpy(z).to(dev), torch.from_numpy(y).to(dev), ks).cpu().numpy()
+        want = oracle.accuracy(z, y, topk=ks)
+        assert [100.0 * float(h) / B for h in got] == pytest.approx(want, abs=1e-9), (trial, B, C, ks)
+
+
 # ------------------------------------------------------------------------------ driver at cfg3 size
 def _eager_train_rlvi(train_loader, model, optimizer, residuals, weights, overfit, threshold, estep="oracle"):
     """The reference's epoch (train_rlvi.py:52-106) as a checker, not a product path: the batch loop is

@@ -39,3 +39,12 @@ for i in range(120):
     ops.stream_copy(a[(i + 6) % 12], a[i % 12])
 torch.cuda.synchronize()
 print("ok")
+# precision@k (topk.hip) at the bench shape and at cfg3's
+for Bk, Ck in ((65536, 100), (4096, 10)):
+    dk = synth.mstep_inputs(Bk, Ck, seed=2)
+    zk, yk = torch.from_numpy(dk["logits"]).to(dev), torch.from_numpy(dk["labels"]).to(dev)
+    hk = torch.empty(2, dtype=torch.int32, device=dev)
+    for _ in range(100):
+        ops.topk_hits(zk, yk, (1, min(5, Ck)), out=hk)
+torch.cuda.synchronize()
+print("topk ok")
