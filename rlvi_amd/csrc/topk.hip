@@ -5,7 +5,7 @@
 // streaming M-step kernel produces on the side); this is the stand-alone form for callers that want @5.
 // No softmax, no sort: the rank of the label's logit inside its row is a count,
 //     rank_i = #{c : z_ic > z_iy} + #{c < y : z_ic == z_iy},     hit@k = rank_i < k,
-// one pass over the logits, a wave per row, the counts per k added with integer atomics (order-free: the
+// one pass over the logits, 64 / G rows per wave, the counts per k added with integer atomics (order-free: the
 // same bits every run).  Equal values rank in column order; which of several equal values torch.topk lists
 // first is an implementation detail of the reference, as are logits that differ but whose fp32 softmax
 // values coincide (unpinned; tests/golden/g10_topk.npz holds tie-free rows).
@@ -13,7 +13,7 @@
 
 namespace rlvi {
 
-constexpr int TOPK_THREADS = 256;
+constexpr int TOPK_THREADS = 1024;         // sixteen waves per workgroup: few workgroups, few atomics on the counters
 constexpr int TOPK_WAVES = TOPK_THREADS / WAVE;
 constexpr int TOPK_MAXK = 8;              // k values per call
 
@@ -22,42 +22,84 @@ struct TopkList { int k[TOPK_MAXK]; };
 __device__ __forceinline__ float topk_widen(float v) { return v; }
 __device__ __forceinline__ float topk_widen(uint16_t v) { return bf16_to_f32(v); }
 
+// G = lanes per row (a power of two, chosen by the launcher so that a lane holds at most eight elements of rows up
+// to 512 columns): 64 / G rows per wave at once, their elements asked for BEFORE the label's logit is known (the
+// label -> logit chain is two dependent round trips), longer rows streamed behind it.
 template <typename T>
-__global__ __launch_bounds__(TOPK_THREADS) void topk_hits_kernel(const T *__restrict__ logits, int64_t ld,
+__global__ __launch_bounds__(TOPK_THREADS, 1) void topk_hits_kernel(const T *__restrict__ logits, int64_t ld,
                                                                  const int64_t *__restrict__ labels, int64_t B, int C,
-                                                                 TopkList ks, int nk, int32_t *__restrict__ hits) {
+                                                                 int G, TopkList ks, int nk, int32_t *__restrict__ hits) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
+    const int R = WAVE / G;
+    const int g = lane & (G - 1), sub = lane / G;
     int mine[TOPK_MAXK];
 #pragma unroll
     for (int j = 0; j < TOPK_MAXK; ++j) mine[j] = 0;
-    const int64_t stride = (int64_t)gridDim.x * TOPK_WAVES;
-    for (int64_t row = (int64_t)blockIdx.x * TOPK_WAVES + wave; row < B; row += stride) {
-        const T *z = logits + row * ld;
-        const int64_t y64 = labels[row];
-        const bool ok = y64 >= 0 && y64 < C;        // a label outside [0, C) matches no prediction (utils.py:72)
-        const int y = ok ? (int)y64 : 0;
-        const float zy = topk_widen(z[y]);
-        int ahead = 0;
-        for (int c = lane; c < C; c += WAVE) {
-            const float v = topk_widen(z[c]);
-            ahead += (v > zy || (v == zy && c < y)) ? 1 : 0;
-        }
-        ahead = group_allreduce<WAVE>(ahead, FAdd());
+    const bool in_regs = C <= 8 * G;
+    const int64_t stride = (int64_t)gridDim.x * TOPK_WAVES * R;
+    for (int64_t row0 = ((int64_t)blockIdx.x * TOPK_WAVES + wave) * R; row0 < B; row0 += stride) {
+        const int64_t row = row0 + sub;
+        const bool valid = row < B;
+        const T *z = logits + (valid ? row : B - 1) * ld;
+        const int64_t y64 = labels[valid ? row : B - 1];
+        float v[8];
+        if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < TOPK_MAXK; ++j) mine[j] += (j < nk && ok && ahead < ks.k[j]) ? 1 : 0;
+            for (int j = 0; j < 8; ++j) {
+                const int c = g + j * G;
+                v[j] = topk_widen(z[c < C ? c : g < C ? g : 0]);
+            }
+        }
+        const bool ok = valid && y64 >= 0 && y64 < C;   // a label outside [0, C) matches no prediction (utils.py:72)
+        const int y = ok ? (int)y64 : 0;
+        int ahead = 0;
+        float zy;
+        if (in_regs) {
+            // the label's logit is already in the registers of one lane of the row's group: no second, dependent load
+            const int jy = y / G, gy = y & (G - 1);
+            float cand = v[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) cand = j == jy ? v[j] : cand;
+            zy = __shfl(cand, sub * G + gy, WAVE);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = g + j * G;
+                ahead += (c < C && (v[j] > zy || (v[j] == zy && c < y))) ? 1 : 0;
+            }
+        } else {
+            zy = topk_widen(z[y]);
+            for (int c = g; c < C; c += G) {
+                const float x = topk_widen(z[c]);
+                ahead += (x > zy || (x == zy && c < y)) ? 1 : 0;
+            }
+        }
+        for (int m = 1; m < G; m <<= 1) ahead += __shfl_xor(ahead, m, WAVE);
+#pragma unroll
+        for (int j = 0; j < TOPK_MAXK; ++j) mine[j] += (j < nk && g == 0 && ok && ahead < ks.k[j]) ? 1 : 0;
     }
+#pragma unroll
+    for (int j = 0; j < TOPK_MAXK; ++j) mine[j] = group_allreduce<WAVE>(mine[j], FAdd());
     __shared__ int sh[TOPK_WAVES][TOPK_MAXK];
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < TOPK_MAXK; ++j) sh[wave][j] = mine[j];
     }
     __syncthreads();
+    // one 64-bit add per PAIR of counters where the array allows it (counts stay below 2^31: no carry between halves)
+    const bool pairs = ((uintptr_t)hits & 7) == 0;
     if (threadIdx.x < nk) {
         int t = 0;
 #pragma unroll
         for (int w = 0; w < TOPK_WAVES; ++w) t += sh[w][threadIdx.x];
-        if (t) atomicAdd(hits + threadIdx.x, t);
+        const int j = threadIdx.x;
+        const int tn = __shfl_down(t, 1, WAVE);                       // (nk <= 8: all in wave 0)
+        if (pairs && (j & 1) == 0 && j + 1 < nk) {
+            const unsigned long long both = (unsigned long long)(unsigned)t | ((unsigned long long)(unsigned)tn << 32);
+            if (both) atomicAdd(reinterpret_cast<unsigned long long *>(hits + j), both);
+        } else if (!(pairs && (j & 1) == 1) && t) {
+            atomicAdd(hits + j, t);
+        }
     }
 }
 
@@ -75,11 +117,14 @@ static int topk_entry(const T *logits, int64_t ld, const int64_t *labels, int64_
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(hits, 0, (size_t)nk * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
-    int64_t nb = (B + TOPK_WAVES - 1) / TOPK_WAVES;
-    const int64_t cap = (int64_t)device_info().cus * 8;
+    int G = 1;
+    while (G < WAVE && C > 8 * (int64_t)G) G <<= 1;
+    const int64_t rows_per_block = (int64_t)TOPK_WAVES * (WAVE / G);
+    int64_t nb = (B + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = (int64_t)device_info().cus;
     if (nb > cap) nb = cap;
-    return launch(topk_hits_kernel<T>, dim3((unsigned)nb), dim3(TOPK_THREADS), 0, st, logits, ld, labels, B, (int)C, kl,
-                  nk, hits);
+    return launch(topk_hits_kernel<T>, dim3((unsigned)nb), dim3(TOPK_THREADS), 0, st, logits, ld, labels, B, (int)C, G,
+                  kl, nk, hits);
 }
 
 }  // namespace rlvi
