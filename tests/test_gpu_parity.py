@@ -1260,7 +1260,7 @@ def test_linear_regression_random_shapes_vs_oracle(gpu, oracle):
     """Forty seeded random shapes (1 <= d <= 31, n up to 4096), contaminations (0 ... 45 %), tail weights and target
     scales through the one launch against the oracle -- well-posed ones: at least d + 8 clean samples (nearer to
     interpolation the weighted system loses its numerical rank and the outcome hangs on the solver's singular-value
-    cutoff: tools/lab/fuzz_linreg.py lists those)."""
+    cutoff: tests/lab/fuzz_linreg.py lists those)."""
     torch, ops, dev = gpu
     rng = np.random.default_rng(2024)
     done = 0
