@@ -96,7 +96,7 @@ int rlvi_workspace_clear_status(void *ws, void *stream);
 int rlvi_workspace_set_option(void *ws, const char *name, int value);
 /* Which form the last M-step launch on this workspace took (tests of the dispatch): 0 none yet, 1 register rows,
  * 2 wave tiles in four-wave workgroups, 3 wave tiles in 16-wave workgroups, 4 word-wise bf16 wave tiles (odd row
- * lengths), 5 long rows (more than 512 vectors per row: one wave per row, three passes); + 16 with a timed hold. */
+ * lengths), 5 long rows (more than 512 vectors per row: a wave or a workgroup per row, three passes); + 16 with a timed hold. */
 int rlvi_workspace_last_mstep_form(const void *ws);
 /* Forget the guesses earlier calls left for the next one (E-step trajectory and minimum, threshold key). */
 int rlvi_workspace_reset_warm(void *ws, void *stream);
@@ -118,7 +118,8 @@ size_t rlvi_workspace_region(const char *name, size_t *bytes);
  *   out         [4] fp32 device: { sum_i pi_i*l_i * inv_scale, 100*hits/B, sum_i pi_i*l_i, hits }
  * bf16 variant: logits / grad_logits are bfloat16, arithmetic is fp32 on the widened values.
  * Any C up to 2^20 (RLVI_E_LIMIT beyond); rows of more than 512 vectors (C > 2048 fp32 / 4096 bf16 with aligned
- * rows, C > 512 with an odd length or pitch) take a one-wave-per-row form that reads the row three times.
+ * rows, C > 512 with an odd length or pitch) take a form that reads the row three times (a wave per row, a workgroup
+ * per row for batches of up to four rows per CU).
  *
  * Evaluation form: weights == NULL (then idx and residuals must be NULL too) computes the plain
  * mean CE and the top-1 percentage of the batch -- utils.evaluate (deep-learning/utils.py:48-62)

@@ -309,78 +309,134 @@ __global__ __launch_bounds__(MSTEP_THREADS) void mstep_kernel(
 // ImageNet-21k head, a padded pitch): a row does not fit a wave's registers, so ONE WAVE walks its row three times
 // from global memory (the second and third pass are L2 hits): maximum -- sum of exponentials, label logit and the
 // ties in front of the label -- gradient.  Same arithmetic and the same records as the register-row kernel.
-template <typename T, int V>
+// WPR = waves per row: 1 (a wave per row: many rows) or MSTEP_WAVES (the whole workgroup on one row: batches of
+// fewer rows than the chip has wave slots -- 256 x 21 841 is 256 rows).  Four vectors per lane in flight per trip.
+template <typename T, int V, int WPR>
 __global__ __launch_bounds__(MSTEP_THREADS) void mstep_longrow_kernel(
     const T *__restrict__ logits, int64_t ld, const int64_t *__restrict__ labels,
     const int64_t *__restrict__ idx, const float *__restrict__ weights,
     float *__restrict__ residuals, int64_t N, int64_t B, int C, float inv_scale,
     T *__restrict__ grad, int64_t ldg, double *__restrict__ part, int32_t *__restrict__ status,
     int accum, double inv_rows100) {
+    constexpr int U = 4;                                          // vectors per lane and trip
+    constexpr int RPB = MSTEP_WAVES / WPR;                        // rows per workgroup at a time
+    constexpr int STEP = WPR * WAVE;                              // lanes on one row
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
+    const int t = WPR == 1 ? lane : threadIdx.x;                  // this thread's position on its row
+    __shared__ float shf[2][MSTEP_WAVES];
+    __shared__ int shi[MSTEP_WAVES];
     float acc = 0.0f, hits = 0.0f;
     bool bad = false;
     const int nv = C / V;                                         // (V divides C)
-    const int64_t stride = (int64_t)gridDim.x * MSTEP_WAVES;
-    for (int64_t row = (int64_t)blockIdx.x * MSTEP_WAVES + wave; row < B; row += stride) {
-        const T *zrow = logits + row * ld;
-        int64_t y64 = labels[row];
-        int64_t ix = idx != nullptr ? idx[row] : row;
-        bool row_ok = true;
-        if (y64 < 0 || y64 >= C) { y64 = 0; bad = true; row_ok = false; }
-        if (ix < 0 || ix >= N) { ix = 0; bad = true; row_ok = false; }
+    const int64_t stride = (int64_t)gridDim.x * RPB;
+    // (every thread of a workgroup runs the same number of trips: the barriers below are uniform)
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += stride) {
+        const int64_t row = row0 + (WPR == 1 ? wave : 0);
+        const bool valid = row < B;
+        const int64_t rr = valid ? row : B - 1;                   // a wave without a row recomputes the last one, stores nothing
+        const T *zrow = logits + rr * ld;
+        int64_t y64 = labels[rr];
+        int64_t ix = idx != nullptr ? idx[rr] : rr;
+        bool row_ok = valid;
+        if (y64 < 0 || y64 >= C) { y64 = 0; bad = bad || valid; row_ok = false; }
+        if (ix < 0 || ix >= N) { ix = 0; bad = bad || valid; row_ok = false; }
         const int y = (int)y64;
         const float pi = weights != nullptr ? weights[ix] : 1.0f;
         float zy;
         {
-            float t[1];
-            VecIO<T, 1>::load(zrow + y, t);
-            zy = t[0];
+            float tt[1];
+            VecIO<T, 1>::load(zrow + y, tt);
+            zy = tt[0];
         }
+        // ---- pass 1: the row maximum
         float m = -__builtin_inff();
-        for (int k = lane; k < nv; k += WAVE) {
-            float v[V];
-            VecIO<T, V>::load(zrow + (size_t)k * V, v);
+        for (int k0 = t; k0 < nv; k0 += STEP * U) {
+            float v[U][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) m = fmaxf(m, v[j]);
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * STEP;
+                VecIO<T, V>::load(zrow + (size_t)(k < nv ? k : k0) * V, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) m = fmaxf(m, v[u][j]);      // (a slot past the end repeats k0: harmless for a maximum)
         }
         m = group_max<WAVE>(m);
+        if (WPR > 1) {
+            if (lane == 0) shf[0][wave] = m;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < MSTEP_WAVES; ++w) m = fmaxf(m, shf[0][w]);
+        }
+        // ---- pass 2: the sum of exponentials and the ties in front of the label
         float s = 0.0f;
         int earlier = 0;
-        for (int k = lane; k < nv; k += WAVE) {
-            float v[V];
-            VecIO<T, V>::load(zrow + (size_t)k * V, v);
+        for (int k0 = t; k0 < nv; k0 += STEP * U) {
+            float v[U][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                s += mexp(v[j] - m);
-                earlier += (v[j] == m && k * V + j < y) ? 1 : 0;
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * STEP;
+                VecIO<T, V>::load(zrow + (size_t)(k < nv ? k : k0) * V, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * STEP;
+                const bool in = k < nv;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    s += in ? mexp(v[u][j] - m) : 0.0f;
+                    earlier += (in && v[u][j] == m && k * V + j < y) ? 1 : 0;
+                }
             }
         }
         s = group_sum<WAVE>(s);
         earlier = group_allreduce<WAVE>(earlier, FAdd());
+        if (WPR > 1) {
+            if (lane == 0) { shf[1][wave] = s; shi[wave] = earlier; }
+            __syncthreads();
+            s = 0.0f;
+            earlier = 0;
+#pragma unroll
+            for (int w = 0; w < MSTEP_WAVES; ++w) { s += shf[1][w]; earlier += shi[w]; }
+        }
         const float li = logf(s) - (zy - m);
-        if (grad != nullptr) {
+        // ---- pass 3: the gradient
+        if (grad != nullptr && valid) {
             const float gs = row_ok ? pi * inv_scale : 0.0f;
             const float inv_s = gs / s;
-            T *grow = grad + row * ldg;
-            for (int k = lane; k < nv; k += WAVE) {
-                float v[V], o[V];
-                VecIO<T, V>::load(zrow + (size_t)k * V, v);
+            T *grow = grad + rr * ldg;
+            for (int k0 = t; k0 < nv; k0 += STEP * U) {
+                float v[U][V];
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    float p = mexp(v[j] - m) * inv_s;
-                    if (k * V + j == y) p -= gs;
-                    o[j] = p;
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u * STEP;
+                    VecIO<T, V>::load(zrow + (size_t)(k < nv ? k : k0) * V, v[u]);
                 }
-                VecIO<T, V>::store_stream(grow + (size_t)k * V, o);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u * STEP;
+                    if (k < nv) {
+                        float o[V];
+#pragma unroll
+                        for (int j = 0; j < V; ++j) {
+                            float p = mexp(v[u][j] - m) * inv_s;
+                            if (k * V + j == y) p -= gs;
+                            o[j] = p;
+                        }
+                        VecIO<T, V>::store_stream(grow + (size_t)k * V, o);
+                    }
+                }
             }
         }
         const bool hit = zy == m && earlier == 0;
-        if (lane == 0 && row_ok) {
+        if (t == 0 && row_ok) {
             if (residuals != nullptr) residuals[ix] = li;
             acc += li * pi;
             hits += hit ? 1.0f : 0.0f;
         }
+        if (WPR > 1) __syncthreads();                             // (shf / shi are rewritten by the next row)
     }
     double a = wave_sum((double)acc);
     double h = wave_sum((double)hits);
@@ -1115,15 +1171,20 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
     if (!force_g && gsel < 64 && (nv + gsel - 1) / gsel >= 2 && (B * gsel + 63) / 64 < 1024) gsel *= 2;
     const int k = (nv + gsel - 1) / gsel;
     if (k > 8) {
-        // more than 512 vectors per row: one wave per row, three passes (mstep_longrow_kernel)
+        // more than 512 vectors per row: a wave (or, for few rows, a workgroup) per row, three passes (mstep_longrow_kernel)
         char *base = static_cast<char *>(ws);
         double *part = reinterpret_cast<double *>(base + (out == nullptr ? WS_PART_OFF : WS_PART2_OFF));
-        int64_t nb = (B + MSTEP_WAVES - 1) / MSTEP_WAVES;
+        // fewer rows than four per CU: the whole workgroup on one row
+        const bool wide = B <= 4 * (int64_t)device_info().cus;
+        int64_t nb = wide ? B : (B + MSTEP_WAVES - 1) / MSTEP_WAVES;
         if (nb > MSTEP_MAX_BLOCKS) nb = MSTEP_MAX_BLOCKS;
         ws_note_mstep(ws, 5);
-        const int rc = launch(mstep_longrow_kernel<T, V>, dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st, logits, ld,
-                              labels, idx, weights, residuals, N, B, C, inv_scale, grad, ldg, part,
-                              reinterpret_cast<int32_t *>(base), out == nullptr ? 1 : 0, 100.0 / (double)B);
+        const int rc = wide ? launch(mstep_longrow_kernel<T, V, MSTEP_WAVES>, dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st,
+                                     logits, ld, labels, idx, weights, residuals, N, B, C, inv_scale, grad, ldg, part,
+                                     reinterpret_cast<int32_t *>(base), out == nullptr ? 1 : 0, 100.0 / (double)B)
+                            : launch(mstep_longrow_kernel<T, V, 1>, dim3((unsigned)nb), dim3(MSTEP_THREADS), 0, st,
+                                     logits, ld, labels, idx, weights, residuals, N, B, C, inv_scale, grad, ldg, part,
+                                     reinterpret_cast<int32_t *>(base), out == nullptr ? 1 : 0, 100.0 / (double)B);
         if (rc != 0 || out == nullptr) return rc;
         return launch(mstep_finalize_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 1.0, out, 1);
     }

@@ -151,9 +151,10 @@ def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     (1029, 104, "bf16"),     # eight lanes x two 8-element vectors, register rows
     (20005, 104, "bf16"),    # four lanes per row, wave tiles
     (3000, 200, "bf16"),
-    (301, 3000, "f32"),      # long rows (more than 512 vectors): one wave per row, three passes
+    (301, 3000, "f32"),      # long rows (more than 512 vectors), three passes; up to 1024 rows: a workgroup per row
     (70, 21841, "f32"),      # ... an odd ImageNet-21k head, single elements
-    (1030, 513, "f32"),      # ... the shortest odd row that takes it
+    (1030, 513, "f32"),      # ... the shortest odd row that takes it; more than 1024 rows: a wave per row
+    (1100, 2052, "f32"),     # ... 16-byte vectors, a wave per row
     (130, 4104, "bf16"),     # ... bf16, 8-element vectors
     (257, 1001, "bf16"),     # ... bf16, single elements
 ])
