@@ -1144,9 +1144,16 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
 #define RLVI_CASE(G_, K_)                                                                        \
     return launch_mstep<T, V, G_, K_>(logits, ld, labels, idx, weights, residuals, N, B, C,      \
                                       (nv + G_ - 1) / G_, inv_scale, grad, ldg, out, ws, st)
+    // (bf16 in 16-byte vectors: at most FOUR vectors = 32 elements per lane, as fp32's eight -- with 64 elements a lane's
+    //  serial work and its registers cost more than the shorter reductions save: tools/lab/sweep_g_bf16.sh, 16 384 x 256
+    //  11.2 -> 6.5 us, x 512 15.8 -> 8.6, x 1000 24.3 -> 15.8, x 2000 39.5 -> 26.7, 4096 x 1000 10.8 -> 6.6)
+    //  Rows of up to 20 vectors keep the 16-row tile with four lanes per row: five vectors per lane there beat three on
+    //  eight lanes, 65 536 x 136 10.6 against 13.3 us, x 160 11.1 against 13.7; x 200 -- seven -- 15.7 against 14.4.)
+    constexpr bool WIDE_BF16 = sizeof(T) == 2 && V == 8;
+    const int kpref = (WIDE_BF16 && nv > 20) ? 4 : 8;
     int gsel = 64;
     for (int gg = 1; gg <= 64; gg <<= 1)
-        if ((nv + gg - 1) / gg <= 8) { gsel = gg; break; }
+        if ((nv + gg - 1) / gg <= kpref) { gsel = gg; break; }
     // 64-row tiles (G = 4) measured best whenever a row has at least 8 vectors (fp32 C = 100:
     // 10.8 us against 11.8 for G = 8; bf16 C = 104: 8.7 us against 12.3 for G = 2)
     if (gsel < 4 && nv >= 8) gsel = 4;
@@ -1168,7 +1175,7 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
     // a launch of less than one wave per SIMD is as long as ONE wave's instruction stream (a lone wave issues
     // an instruction every ~6 clocks): twice the lanes per row halve it (tools/sweep_small.sh: 4096 x 10
     // 3.65 -> 3.3 us, 4096 x 100 4.4 -> 4.05, 1024 x 101 3.35 -> 3.1; from 1024 waves on the wider tile wins)
-    if (!force_g && gsel < 64 && (nv + gsel - 1) / gsel >= 2 && (B * gsel + 63) / 64 < 1024) gsel *= 2;
+    if (!force_g && kpref == 8 && gsel < 64 && (nv + gsel - 1) / gsel >= 2 && (B * gsel + 63) / 64 < 1024) gsel *= 2;
     const int k = (nv + gsel - 1) / gsel;
     if (k > 8) {
         // more than 512 vectors per row: a wave (or, for few rows, a workgroup) per row, three passes (mstep_longrow_kernel)
