@@ -1171,6 +1171,21 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
             if (k4 <= 16) RLVI_CASE(4, 16);
             if constexpr (V == 1) RLVI_CASE(4, 32);
         }
+        // the same for rows of 129 ... 512 such elements (Places365's 365 classes): sixteen lanes per row, four rows per
+        // wave tile, instead of one row per wave in single 4-byte loads (lab knob RLVI_MSTEP_ODD16=0: the old route)
+        // -- 65 536 x 365 fp32 46.0 -> 39.5 us, 16 384 x 365 15.5 -> 11.8, 65 536 x 201 27.9 -> 22.1, 65 536 x 366 bf16
+        // 30.9 -> 24.4; not below 8192 rows (4096 x 365: 5.9 against 7.2) and not beyond 24 single elements per lane (x 511:
+        // 54.6 against 58.0, the 32-slot form spills)
+        if (gsel > 16 && C > 128 && C <= 512 && !force_g && B >= tune_get("RLVI_MSTEP_ODD16_ROWS", 8192) &&
+            tune_get("RLVI_MSTEP_ODD16", 1)) {
+            const int k16 = (nv + 15) / 16;
+            if constexpr (!(sizeof(T) == 2 && V == 4)) {         // (bf16 in 8-byte vectors never has gsel > 16 here)
+                if (k16 <= 16) RLVI_CASE(16, 16);
+            }
+            if constexpr (V == 1) {
+                if (k16 <= 24) RLVI_CASE(16, 24);
+            }
+        }
     }
     // a launch of less than one wave per SIMD is as long as ONE wave's instruction stream (a lone wave issues
     // an instruction every ~6 clocks): twice the lanes per row halve it (tools/sweep_small.sh: 4096 x 10

@@ -151,6 +151,11 @@ def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     (1029, 104, "bf16"),     # eight lanes x two 8-element vectors, register rows
     (20005, 104, "bf16"),    # four lanes per row, wave tiles
     (3000, 200, "bf16"),
+    (20003, 365, "f32"),     # odd rows of 129 ... 384 elements from 8192 rows on: sixteen lanes per row, 24 single elements each
+    (9001, 201, "f32"),      # ... 16 single elements per lane
+    (8200, 366, "f32"),      # ... even but no multiple of four: two-element vectors
+    (8200, 366, "bf16"),     # ... bf16 pairs
+    (9001, 365, "bf16"),     # (odd bf16 rows beyond 127 elements stay on the register rows)
     (301, 3000, "f32"),      # long rows (more than 512 vectors), three passes; up to 1024 rows: a workgroup per row
     (70, 21841, "f32"),      # ... an odd ImageNet-21k head, single elements
     (1030, 513, "f32"),      # ... the shortest odd row that takes it; more than 1024 rows: a wave per row
