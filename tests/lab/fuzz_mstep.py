@@ -15,12 +15,18 @@ from rlvi_amd import _lib, ops, synth  # noqa: E402
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+dense_mode = len(sys.argv) > 3 and sys.argv[3] == "dense"
 REL = 1e-5
 bad = 0
 forms = {}
 ws = ops.Workspace(dev, 80000, 80000)
 for c in range(cases):
-    if rng.random() < 0.35:                                   # chip-filling launches: the wave-tile forms
+    if dense_mode:                                            # (argv[3] = dense) dense launches of 8192 ... 70 000 rows: the tile forms
+        B = int(rng.integers(8192, 70001))
+        C = int(rng.integers(1, 521))
+        if B * C > 12_000_000:
+            B = max(8192, 12_000_000 // C)
+    elif rng.random() < 0.35:                                 # chip-filling launches: the wave-tile forms
         B = int(rng.integers(20000, 70001))
         C = int(rng.integers(1, 161))
     else:
@@ -29,8 +35,8 @@ for c in range(cases):
     if B * C > 12_000_000:
         B = max(1, 12_000_000 // C)
     dtype = "bf16" if rng.random() < 0.4 else "f32"
-    pad_in = int(rng.choice([0, 0, 1, 3, 4, 8]))
-    pad_g = int(rng.choice([0, 0, 2, 4, 8]))
+    pad_in = 0 if dense_mode else int(rng.choice([0, 0, 1, 3, 4, 8]))
+    pad_g = 0 if dense_mode else int(rng.choice([0, 0, 2, 4, 8]))
     want_grad = rng.random() < 0.85
     accumulate = rng.random() < 0.4
     N = B + int(rng.integers(0, 50))
