@@ -1191,10 +1191,11 @@ static int dispatch_gk(const T *logits, int64_t ld, const int64_t *labels, const
     // an instruction every ~6 clocks): twice the lanes per row halve it (tools/sweep_small.sh: 4096 x 10
     // 3.65 -> 3.3 us, 4096 x 100 4.4 -> 4.05, 1024 x 101 3.35 -> 3.1; from 1024 waves on the wider tile wins)
     if (!force_g && kpref == 8 && gsel < 64 && (nv + gsel - 1) / gsel >= 2 && (B * gsel + 63) / 64 < 1024) gsel *= 2;
-    // rows of five to eight 16-byte vectors (fp32 C = 20 ... 32, bf16 C = 40 ... 64) from 16 384 rows on: two lanes per row
-    // (32 rows per wave tile) -- 65 536 x 32 fp32 6.75 -> 6.2 us, x 24 6.5 -> 5.7, bf16 x 64 8.6 -> 7.1, x 48 10.6 -> 7.0,
-    // 262 144 x 64 bf16 22.5 -> 18.2; nine vectors (x 36 / x 72) are better off with four lanes, four (x 16 / x 32) with one
-    if (!force_g && V * sizeof(T) == 16 && nv >= 5 && nv <= 8 && B >= 16384) gsel = 2;
+    // bf16 rows of five to eight 16-byte vectors (C = 40 ... 64) from 16 384 rows on: two lanes per row (32 rows per wave
+    // tile) -- 65 536 x 64 8.6 -> 7.1 us, x 48 10.6 -> 7.0, x 40 10.5 -> 6.8, 262 144 x 64 22.5 -> 18.2; nine vectors (x 72) are
+    // better off with four lanes, four (x 32) with one.  (fp32 C = 20 ... 32 would gain 8-12 % too -- 65 536 x 32 6.75 -> 6.2 us --
+    // but the one-launch in-batch E+M promises the bits of this kernel's four-lane row sums at those shapes.)
+    if (!force_g && sizeof(T) == 2 && V == 8 && nv >= 5 && nv <= 8 && B >= 16384) gsel = 2;
     const int k = (nv + gsel - 1) / gsel;
     if (k > 8) {
         // more than 512 vectors per row: a wave (or, for few rows, a workgroup) per row, three passes (mstep_longrow_kernel)

@@ -156,8 +156,8 @@ def test_mstep_vs_oracle_shapes(B, C, gpu, oracle):
     (8200, 366, "f32"),      # ... even but no multiple of four: two-element vectors
     (8200, 366, "bf16"),     # ... bf16 pairs
     (9001, 365, "bf16"),     # (odd bf16 rows beyond 127 elements stay on the register rows)
-    (20003, 24, "f32"),      # five to eight 16-byte vectors per row from 16 384 rows on: two lanes per row, 32-row tiles
-    (16411, 48, "bf16"),     # ... bf16
+    (16411, 48, "bf16"),     # bf16 rows of five to eight 16-byte vectors from 16 384 rows on: two lanes per row, 32-row tiles
+    (20003, 64, "bf16"),     # ... eight
     (301, 3000, "f32"),      # long rows (more than 512 vectors), three passes; up to 1024 rows: a workgroup per row
     (70, 21841, "f32"),      # ... an odd ImageNet-21k head, single elements
     (1030, 513, "f32"),      # ... the shortest odd row that takes it; more than 1024 rows: a wave per row
